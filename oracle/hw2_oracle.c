@@ -1,0 +1,668 @@
+/*
+ * hw2_oracle.c -- TEST INFRASTRUCTURE ONLY (see hw2_oracle.h).
+ *
+ * Plain-C restatement of /root/reference/Local_Global_Alignment/hw2.cpp.
+ * Nothing here is shipped or measured as the product; it is the checker the
+ * HIP path is compared with, and (bench.py cpu_baseline, kind "port") a timed
+ * single-thread CPU baseline that keeps the reference's data structures:
+ * one int matrix + one char matrix of (n+1)(m+1) cells, filled row-major.
+ */
+#include "hw2_oracle.h"
+
+#include <ctype.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- helpers */
+
+typedef struct strbuf {
+    char *p;
+    size_t len, cap;
+} strbuf;
+
+static void sb_reserve(strbuf *s, size_t extra) {
+    if (s->len + extra + 1 > s->cap) {
+        size_t nc = s->cap ? s->cap * 2 : 64;
+        while (nc < s->len + extra + 1) nc *= 2;
+        s->p = (char *)realloc(s->p, nc);
+        s->cap = nc;
+    }
+}
+static void sb_putc(strbuf *s, char c) {
+    sb_reserve(s, 1);
+    s->p[s->len++] = c;
+    s->p[s->len] = 0;
+}
+static void sb_putn(strbuf *s, const char *src, size_t n) {
+    sb_reserve(s, n);
+    memcpy(s->p + s->len, src, n);
+    s->len += n;
+    s->p[s->len] = 0;
+}
+static void sb_putint(strbuf *s, long v) { /* std::to_string(int) */
+    char tmp[32];
+    int k = snprintf(tmp, sizeof tmp, "%ld", v);
+    sb_putn(s, tmp, (size_t)k);
+}
+static char *sb_finish(strbuf *s) {
+    if (!s->p) {
+        s->p = (char *)malloc(1);
+        s->p[0] = 0;
+    }
+    return s->p;
+}
+
+static inline int32_t wrap_add(int32_t a, int32_t b) { /* int + int as two's complement */
+    return (int32_t)((uint32_t)a + (uint32_t)b);
+}
+static inline int32_t wrap_mul_idx(size_t i, int32_t g) { /* hw2.cpp:126/132 "i * gapPenalty" -> int */
+    return (int32_t)((uint32_t)i * (uint32_t)g);
+}
+
+static void reverse_bytes(char *s, size_t n) {
+    if (n < 2) return;
+    for (size_t a = 0, b = n - 1; a < b; ++a, --b) {
+        char c = s[a];
+        s[a] = s[b];
+        s[b] = c;
+    }
+}
+
+/* ------------------------------------------------- hw2.cpp:59-78 CIGAR RLE */
+char *orc_cigar(const char *ops, size_t n_ops) {
+    strbuf out = {0, 0, 0};
+    if (n_ops == 0) return sb_finish(&out);         /* 60-62 */
+    long count = 1;                                 /* 64 */
+    char current = ops[n_ops - 1];                  /* 65: back() */
+    for (size_t k = n_ops - 1; k-- > 0;) {          /* 67: i = size-2 .. 0 */
+        if (ops[k] == current) {
+            ++count;
+        } else {
+            sb_putint(&out, count);                 /* 71 */
+            sb_putc(&out, current);
+            current = ops[k];
+            count = 1;
+        }
+    }
+    sb_putint(&out, count);                         /* 76 */
+    sb_putc(&out, current);
+    return sb_finish(&out);
+}
+
+/* ------------------------------------------------ hw2.cpp:80-116 MD:Z */
+char *orc_mdz(const char *ap, const char *ar, const char *ops_tb, size_t n_ops) {
+    strbuf out = {0, 0, 0};
+    long match_count = 0;
+    size_t i = 0;
+    /* 81: the op list is reversed in place -> forward order; index it backwards instead */
+#define FWD(k) (ops_tb[n_ops - 1 - (k)])
+    while (i < n_ops) {                             /* 86 */
+        if (FWD(i) == 'M') {                        /* 87 */
+            if (ap[i] == ar[i]) {                   /* 89 */
+                ++match_count;
+            } else {
+                sb_putint(&out, match_count);       /* 93 */
+                sb_putc(&out, ar[i]);               /* 94: the REFERENCE character */
+                match_count = 0;
+            }
+            ++i;
+        } else if (FWD(i) == 'D') {                 /* 98 */
+            sb_putint(&out, match_count);           /* 100 */
+            sb_putc(&out, '^');
+            match_count = 0;
+            while (i < n_ops && FWD(i) == 'D') {    /* 104: run of D, chars from alignedPattern */
+                sb_putc(&out, ap[i]);
+                ++i;
+            }
+        } else {
+            ++i;                                    /* 109-112: 'I' skipped, count untouched */
+        }
+    }
+#undef FWD
+    sb_putint(&out, match_count);                   /* 114 */
+    return sb_finish(&out);
+}
+
+/* ------------------------------------------------ hw2.cpp:267-278 overlap */
+int orc_overlap(const char *ap, const char *ar, size_t len) {
+    int max_match = 0, current = 0;
+    for (size_t i = 0; i < len; ++i) {
+        if (ap[i] != '-' && ar[i] != '-' && ap[i] == ar[i]) {
+            ++current;
+            if (current > max_match) max_match = current;
+        } else {
+            current = 0;
+        }
+    }
+    return max_match;
+}
+
+/* ------------------------------------------------ result assembly
+ * Shared tail of both alignment functions (hw2.cpp:183-188 / 258-263): the walk
+ * produced the gapped strings back-to-front plus the op list in walk order. */
+static orc_result *finish_result(int32_t score, strbuf *ap, strbuf *ar, strbuf *ops, size_t end_i, size_t end_j,
+                                 size_t start_i, size_t start_j) {
+    orc_result *r = (orc_result *)calloc(1, sizeof *r);
+    r->score = score;
+    r->aligned_pattern = sb_finish(ap);
+    r->aligned_reference = sb_finish(ar);
+    r->ops = sb_finish(ops);
+    r->n_ops = ops->len;
+    reverse_bytes(r->aligned_pattern, ap->len);     /* 183 / 258 */
+    reverse_bytes(r->aligned_reference, ar->len);   /* 184 / 259 */
+    r->cigar = orc_cigar(r->ops, r->n_ops);         /* 187 / 262 */
+    r->mdz = orc_mdz(r->aligned_pattern, r->aligned_reference, r->ops, r->n_ops); /* 188 / 263 */
+    r->end_i = end_i;
+    r->end_j = end_j;
+    r->start_i = start_i;
+    r->start_j = start_j;
+    return r;
+}
+
+void orc_free(orc_result *r) {
+    if (!r) return;
+    free(r->aligned_pattern);
+    free(r->aligned_reference);
+    free(r->cigar);
+    free(r->mdz);
+    free(r->ops);
+    free(r);
+}
+
+/* ------------------------------------------------ hw2.cpp:118-190 NW, full matrices */
+orc_result *orc_nw(const char *p, size_t n, const char *t, size_t m, int match, int mismatch, int gap) {
+    const size_t W = m + 1;
+    int32_t *dp = (int32_t *)calloc((n + 1) * W, sizeof(int32_t));   /* 119 */
+    char *tb = (char *)malloc((n + 1) * W);                          /* 120 */
+    if (!dp || !tb) {
+        free(dp);
+        free(tb);
+        return NULL;
+    }
+    memset(tb, ' ', (n + 1) * W);
+    for (size_t i = 0; i <= n; ++i) {                                /* 125-130 */
+        dp[i * W] = wrap_mul_idx(i, gap);
+        if (i > 0) tb[i * W] = 'u';
+    }
+    for (size_t j = 0; j <= m; ++j) {                                /* 131-136 */
+        dp[j] = wrap_mul_idx(j, gap);
+        if (j > 0) tb[j] = 'l';
+    }
+    for (size_t i = 1; i <= n; ++i) {                                /* 138 */
+        const int32_t *prev = dp + (i - 1) * W;
+        int32_t *cur = dp + i * W;
+        char *tbr = tb + i * W;
+        const char pc = p[i - 1];
+        for (size_t j = 1; j <= m; ++j) {                            /* 139 */
+            int32_t up = wrap_add(prev[j], gap);                     /* 140 */
+            int32_t left = wrap_add(cur[j - 1], gap);                /* 141 */
+            int32_t v = wrap_add(prev[j - 1], pc == t[j - 1] ? match : mismatch); /* 142 */
+            char c = 'd';                                            /* 145 */
+            if (left > v) {                                          /* 146-149 */
+                v = left;
+                c = 'l';
+            }
+            if (up > v) {                                            /* 150-153 */
+                v = up;
+                c = 'u';
+            }
+            cur[j] = v;
+            tbr[j] = c;
+        }
+    }
+    size_t ti = n, tj = m;                                           /* 158 */
+    strbuf ap = {0, 0, 0}, ar = {0, 0, 0}, ops = {0, 0, 0};
+    while (ti > 0 || tj > 0) {                                       /* 163 */
+        char c = tb[ti * W + tj];
+        if (ti > 0 && tj > 0 && c == 'd') {                          /* 164 */
+            sb_putc(&ap, p[ti - 1]);
+            sb_putc(&ar, t[tj - 1]);
+            sb_putc(&ops, 'M');
+            --ti;
+            --tj;
+        } else if (ti > 0 && c == 'u') {                             /* 170 */
+            sb_putc(&ap, p[ti - 1]);
+            sb_putc(&ar, '-');
+            sb_putc(&ops, 'D');
+            --ti;
+        } else if (tj > 0 && c == 'l') {                             /* 175 */
+            sb_putc(&ap, '-');
+            sb_putc(&ar, t[tj - 1]);
+            sb_putc(&ops, 'I');
+            --tj;
+        }
+    }
+    int32_t score = dp[n * W + m];                                   /* 186 */
+    free(dp);
+    free(tb);
+    return finish_result(score, &ap, &ar, &ops, n, m, 0, 0);
+}
+
+/* ------------------------------------------------ hw2.cpp:192-265 SW, full matrices */
+orc_result *orc_sw(const char *p, size_t n, const char *t, size_t m, int match, int mismatch, int gap) {
+    const size_t W = m + 1;
+    int32_t *dp = (int32_t *)calloc((n + 1) * W, sizeof(int32_t));   /* 193 */
+    char *tb = (char *)malloc((n + 1) * W);                          /* 194 */
+    if (!dp || !tb) {
+        free(dp);
+        free(tb);
+        return NULL;
+    }
+    memset(tb, ' ', (n + 1) * W);
+    int32_t best = 0;                                                /* 202 */
+    size_t ti = 0, tj = 0;                                           /* 203 */
+    for (size_t i = 1; i <= n; ++i) {                                /* 205 */
+        const int32_t *prev = dp + (i - 1) * W;
+        int32_t *cur = dp + i * W;
+        char *tbr = tb + i * W;
+        const char pc = p[i - 1];
+        for (size_t j = 1; j <= m; ++j) {                            /* 206 */
+            int32_t diagonal = wrap_add(prev[j - 1], pc == t[j - 1] ? match : mismatch); /* 208 */
+            int32_t up = wrap_add(prev[j], gap);                     /* 209 */
+            int32_t left = wrap_add(cur[j - 1], gap);                /* 210 */
+            int32_t v = up > left ? up : left;                       /* 211 */
+            if (diagonal > v) v = diagonal;
+            if (v < 0) v = 0;
+            char c;
+            if (v == 0) c = '0';                                     /* 214 */
+            else if (v == diagonal) c = 'd';                         /* 216 */
+            else if (v == up) c = 'u';                               /* 218 */
+            else c = 'l';                                            /* 220 */
+            cur[j] = v;
+            tbr[j] = c;
+            if (v > best) {                                          /* 225-229: strict, row-major first */
+                best = v;
+                ti = i;
+                tj = j;
+            }
+        }
+    }
+    const size_t end_i = ti, end_j = tj;
+    strbuf ap = {0, 0, 0}, ar = {0, 0, 0}, ops = {0, 0, 0};
+    while (ti > 0 && tj > 0 && dp[ti * W + tj] != 0) {               /* 239 */
+        char c = tb[ti * W + tj];
+        if (c == 'd') {                                              /* 240 */
+            sb_putc(&ap, p[ti - 1]);
+            sb_putc(&ar, t[tj - 1]);
+            sb_putc(&ops, 'M');
+            --ti;
+            --tj;
+        } else if (c == 'u') {                                       /* 246 */
+            sb_putc(&ap, p[ti - 1]);
+            sb_putc(&ar, '-');
+            sb_putc(&ops, 'D');
+            --ti;
+        } else if (c == 'l') {                                       /* 251 */
+            sb_putc(&ap, '-');
+            sb_putc(&ar, t[tj - 1]);
+            sb_putc(&ops, 'I');
+            --tj;
+        }
+    }
+    free(dp);
+    free(tb);
+    return finish_result(best, &ap, &ar, &ops, end_i, end_j, ti, tj);
+}
+
+/* ------------------------------------------------ compact forms (rolling rows + 1 B/cell codes) */
+orc_result *orc_nw_compact(const char *p, size_t n, const char *t, size_t m, int match, int mismatch, int gap) {
+    const size_t W = m + 1;
+    int32_t *row = (int32_t *)malloc(W * sizeof(int32_t));
+    char *tb = (char *)malloc((n + 1) * W);
+    if (!row || !tb) {
+        free(row);
+        free(tb);
+        return NULL;
+    }
+    tb[0] = ' ';
+    for (size_t j = 0; j <= m; ++j) {
+        row[j] = wrap_mul_idx(j, gap);
+        if (j > 0) tb[j] = 'l';
+    }
+    for (size_t i = 1; i <= n; ++i) {
+        char *tbr = tb + i * W;
+        const char pc = p[i - 1];
+        int32_t diag = row[0];
+        row[0] = wrap_mul_idx(i, gap);
+        tbr[0] = 'u';
+        for (size_t j = 1; j <= m; ++j) {
+            int32_t up = wrap_add(row[j], gap);
+            int32_t left = wrap_add(row[j - 1], gap);
+            int32_t v = wrap_add(diag, pc == t[j - 1] ? match : mismatch);
+            char c = 'd';
+            if (left > v) {
+                v = left;
+                c = 'l';
+            }
+            if (up > v) {
+                v = up;
+                c = 'u';
+            }
+            diag = row[j];
+            row[j] = v;
+            tbr[j] = c;
+        }
+    }
+    size_t ti = n, tj = m;
+    strbuf ap = {0, 0, 0}, ar = {0, 0, 0}, ops = {0, 0, 0};
+    while (ti > 0 || tj > 0) {
+        char c = tb[ti * W + tj];
+        if (ti > 0 && tj > 0 && c == 'd') {
+            sb_putc(&ap, p[ti - 1]);
+            sb_putc(&ar, t[tj - 1]);
+            sb_putc(&ops, 'M');
+            --ti;
+            --tj;
+        } else if (ti > 0 && c == 'u') {
+            sb_putc(&ap, p[ti - 1]);
+            sb_putc(&ar, '-');
+            sb_putc(&ops, 'D');
+            --ti;
+        } else if (tj > 0 && c == 'l') {
+            sb_putc(&ap, '-');
+            sb_putc(&ar, t[tj - 1]);
+            sb_putc(&ops, 'I');
+            --tj;
+        }
+    }
+    int32_t score = row[m];
+    free(row);
+    free(tb);
+    return finish_result(score, &ap, &ar, &ops, n, m, 0, 0);
+}
+
+orc_result *orc_sw_compact(const char *p, size_t n, const char *t, size_t m, int match, int mismatch, int gap) {
+    const size_t W = m + 1;
+    int32_t *row = (int32_t *)calloc(W, sizeof(int32_t));
+    char *tb = (char *)malloc((n + 1) * W);
+    if (!row || !tb) {
+        free(row);
+        free(tb);
+        return NULL;
+    }
+    memset(tb, ' ', W);
+    int32_t best = 0;
+    size_t ti = 0, tj = 0;
+    for (size_t i = 1; i <= n; ++i) {
+        char *tbr = tb + i * W;
+        const char pc = p[i - 1];
+        int32_t diag = 0; /* dp[i-1][0] */
+        tbr[0] = ' ';
+        for (size_t j = 1; j <= m; ++j) {
+            int32_t diagonal = wrap_add(diag, pc == t[j - 1] ? match : mismatch);
+            int32_t up = wrap_add(row[j], gap);
+            int32_t left = wrap_add(row[j - 1], gap); /* row[0] stays 0 = dp[i][0] */
+            int32_t v = up > left ? up : left;
+            if (diagonal > v) v = diagonal;
+            if (v < 0) v = 0;
+            char c;
+            if (v == 0) c = '0';
+            else if (v == diagonal) c = 'd';
+            else if (v == up) c = 'u';
+            else c = 'l';
+            diag = row[j];
+            row[j] = v;
+            tbr[j] = c;
+            if (v > best) {
+                best = v;
+                ti = i;
+                tj = j;
+            }
+        }
+    }
+    const size_t end_i = ti, end_j = tj;
+    strbuf ap = {0, 0, 0}, ar = {0, 0, 0}, ops = {0, 0, 0};
+    /* dp != 0  <=>  code != '0' for every cell with i,j >= 1 (hw2.cpp:214) */
+    while (ti > 0 && tj > 0 && tb[ti * W + tj] != '0') {
+        char c = tb[ti * W + tj];
+        if (c == 'd') {
+            sb_putc(&ap, p[ti - 1]);
+            sb_putc(&ar, t[tj - 1]);
+            sb_putc(&ops, 'M');
+            --ti;
+            --tj;
+        } else if (c == 'u') {
+            sb_putc(&ap, p[ti - 1]);
+            sb_putc(&ar, '-');
+            sb_putc(&ops, 'D');
+            --ti;
+        } else {
+            sb_putc(&ap, '-');
+            sb_putc(&ar, t[tj - 1]);
+            sb_putc(&ops, 'I');
+            --tj;
+        }
+    }
+    free(row);
+    free(tb);
+    return finish_result(best, &ap, &ar, &ops, end_i, end_j, ti, tj);
+}
+
+/* ------------------------------------------------ score-only forms */
+int32_t orc_nw_score(const char *p, size_t n, const char *t, size_t m, int match, int mismatch, int gap) {
+    int32_t *row = (int32_t *)malloc((m + 1) * sizeof(int32_t));
+    for (size_t j = 0; j <= m; ++j) row[j] = wrap_mul_idx(j, gap);
+    for (size_t i = 1; i <= n; ++i) {
+        const char pc = p[i - 1];
+        int32_t diag = row[0];
+        row[0] = wrap_mul_idx(i, gap);
+        for (size_t j = 1; j <= m; ++j) {
+            int32_t up = wrap_add(row[j], gap);
+            int32_t left = wrap_add(row[j - 1], gap);
+            int32_t v = wrap_add(diag, pc == t[j - 1] ? match : mismatch);
+            if (left > v) v = left;
+            if (up > v) v = up;
+            diag = row[j];
+            row[j] = v;
+        }
+    }
+    int32_t s = row[m];
+    free(row);
+    return s;
+}
+
+int32_t orc_sw_score(const char *p, size_t n, const char *t, size_t m, int match, int mismatch, int gap,
+                     size_t *end_i, size_t *end_j) {
+    int32_t *row = (int32_t *)calloc(m + 1, sizeof(int32_t));
+    int32_t best = 0;
+    size_t bi = 0, bj = 0;
+    for (size_t i = 1; i <= n; ++i) {
+        const char pc = p[i - 1];
+        int32_t diag = 0;
+        for (size_t j = 1; j <= m; ++j) {
+            int32_t diagonal = wrap_add(diag, pc == t[j - 1] ? match : mismatch);
+            int32_t up = wrap_add(row[j], gap);
+            int32_t left = wrap_add(row[j - 1], gap);
+            int32_t v = up > left ? up : left;
+            if (diagonal > v) v = diagonal;
+            if (v < 0) v = 0;
+            diag = row[j];
+            row[j] = v;
+            if (v > best) {
+                best = v;
+                bi = i;
+                bj = j;
+            }
+        }
+    }
+    free(row);
+    if (end_i) *end_i = bi;
+    if (end_j) *end_j = bj;
+    return best;
+}
+
+/* ------------------------------------------------ hw2.cpp:25-57 readFasta */
+static int ref_isspace(char c) { /* isspace() in the "C" locale, as line 36 sees it */
+    unsigned char u = (unsigned char)c;
+    return u == ' ' || (u >= '\t' && u <= '\r');
+}
+
+int orc_read_fasta(const char *path, orc_fasta *out) {
+    out->count = 0;
+    out->seq = NULL;
+    out->len = NULL;
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;                                               /* 28-31 */
+    size_t cap = 0;
+    strbuf cur = {0, 0, 0};
+    strbuf line = {0, 0, 0};
+    int c;
+    int at_eof = 0;
+#define PUSH_SEQ()                                                          \
+    do {                                                                    \
+        if (out->count == cap) {                                            \
+            cap = cap ? cap * 2 : 16;                                       \
+            out->seq = (char **)realloc(out->seq, cap * sizeof(char *));    \
+            out->len = (size_t *)realloc(out->len, cap * sizeof(size_t));   \
+        }                                                                   \
+        out->seq[out->count] = (char *)malloc(cur.len + 1);                 \
+        memcpy(out->seq[out->count], cur.p, cur.len);                       \
+        out->seq[out->count][cur.len] = 0;                                  \
+        out->len[out->count] = cur.len;                                     \
+        ++out->count;                                                       \
+        cur.len = 0;                                                        \
+    } while (0)
+    while (!at_eof) {
+        /* std::getline: read up to '\n'; a final line without '\n' still counts if
+         * anything was extracted; an empty extraction at EOF ends the loop (33). */
+        line.len = 0;
+        int got_any = 0;
+        for (;;) {
+            c = fgetc(f);
+            if (c == EOF) {
+                at_eof = 1;
+                break;
+            }
+            got_any = 1;
+            if (c == '\n') break;
+            sb_putc(&line, (char)c);
+        }
+        if (at_eof && !got_any) break;
+        while (line.len > 0 && (line.p[line.len - 1] == '\r' || ref_isspace(line.p[line.len - 1]))) --line.len; /* 35-39 */
+        if (line.len == 0) continue;                                 /* 40-42 */
+        if (line.p[0] == '>') {                                      /* 43 */
+            if (cur.len > 0) PUSH_SEQ();                             /* 44-47 */
+        } else {
+            sb_putn(&cur, line.p, line.len);                         /* 49 */
+        }
+    }
+    if (cur.len > 0) PUSH_SEQ();                                     /* 52-54 */
+#undef PUSH_SEQ
+    free(cur.p);
+    free(line.p);
+    fclose(f);
+    return 0;
+}
+
+void orc_free_fasta(orc_fasta *f) {
+    for (size_t i = 0; i < f->count; ++i) free(f->seq[i]);
+    free(f->seq);
+    free(f->len);
+    f->seq = NULL;
+    f->len = NULL;
+    f->count = 0;
+}
+
+/* ------------------------------------------------ hw2.cpp:280-403 main */
+int orc_hw2_main(int argc, char **argv) {
+    if (argc < 9) {                                                  /* 281-284 */
+        fprintf(stderr,
+                "Usage: %s -g|-l -p <patterns.fasta> -t <texts.fasta> -o <output.txt> -s <match> <mismatch> <gap>\n",
+                argv[0]);
+        return 1;
+    }
+    int global = 0, local = 0;
+    const char *pattern_file = "", *reference_file = "", *output_file = "";
+    int match = 0, mismatch = 0, gap = 0;
+    for (int i = 1; i < argc; ++i) {                                 /* 290-307 */
+        const char *a = argv[i];
+        if (strcmp(a, "-g") == 0) global = 1;
+        else if (strcmp(a, "-l") == 0) local = 1;
+        else if (strcmp(a, "-p") == 0 && i + 1 < argc) pattern_file = argv[++i];
+        else if (strcmp(a, "-t") == 0 && i + 1 < argc) reference_file = argv[++i];
+        else if (strcmp(a, "-o") == 0 && i + 1 < argc) output_file = argv[++i];
+        else if (strcmp(a, "-s") == 0 && i + 3 < argc) {
+            match = atoi(argv[++i]);
+            mismatch = atoi(argv[++i]);
+            gap = atoi(argv[++i]);
+        }
+    }
+    orc_fasta pats, refs;
+    if (orc_read_fasta(pattern_file, &pats) != 0) {                  /* 317 -> 28-31 */
+        fprintf(stderr, "Error: Cannot open file %s\n", pattern_file);
+        return 1; /* exit(1) */
+    }
+    if (orc_read_fasta(reference_file, &refs) != 0) {                /* 318 */
+        fprintf(stderr, "Error: Cannot open file %s\n", reference_file);
+        orc_free_fasta(&pats);
+        return 1;
+    }
+    if (pats.count != refs.count) {                                  /* 319-322 */
+        fprintf(stderr, "Error: Number of patterns and references do not match.\n");
+        orc_free_fasta(&pats);
+        orc_free_fasta(&refs);
+        return 1;
+    }
+    size_t np = pats.count;
+    orc_result **results = (orc_result **)calloc(np ? np : 1, sizeof *results);
+    for (size_t i = 0; i < np; ++i) {                                /* 328-338 */
+        results[i] = global ? orc_nw(pats.seq[i], pats.len[i], refs.seq[i], refs.len[i], match, mismatch, gap)
+                            : orc_sw(pats.seq[i], pats.len[i], refs.seq[i], refs.len[i], match, mismatch, gap);
+    }
+    int best_score = -1000000, best_index = -1;                      /* 326 */
+    orc_result *best = np ? results[0] : NULL;                       /* 340 */
+    for (size_t i = 0; i < np; ++i) {                                /* 342-357 */
+        if (global) {
+            int ov = orc_overlap(results[i]->aligned_pattern, results[i]->aligned_reference,
+                                 strlen(results[i]->aligned_pattern));
+            if (ov > best_score) {
+                best_score = ov;
+                best = results[i];
+                best_index = (int)i;
+            }
+        } else if (results[i]->score > best_score) {
+            best_score = results[i]->score;
+            best = results[i];
+            best_index = (int)i;
+        }
+    }
+    int rc = 0;
+    FILE *out = fopen(output_file, "wb");                            /* 373 */
+    if (!out) {
+        fprintf(stderr, "Error: Cannot open output file %s\n", output_file); /* 374-377 */
+        rc = 1;
+        /* the reference returns here without freeing; process exit frees */
+    } else {
+        if ((global || local) && best != NULL && best_index >= 0) {  /* 379 / 386 */
+            fprintf(out, "%s\n", global ? "Longest overlap:" : "Highest local alignment score:");
+            fprintf(out, "pattern=%s\n", pats.seq[best_index]);
+            fprintf(out, "reference=%s\n", refs.seq[best_index]);
+            fprintf(out, "Score =%d\n", best->score);
+            fprintf(out, "CIGAR =%s\n", best->cigar);
+            fprintf(out, "MD:Z=%s\n", best->mdz);
+        }
+        fclose(out);
+    }
+    for (size_t i = 0; i < np; ++i) orc_free(results[i]);            /* 395-399 */
+    free(results);
+    orc_free_fasta(&pats);
+    orc_free_fasta(&refs);
+    return rc;
+}
+
+/* ------------------------------------------------ SURVEY.md 8(d) generator */
+static inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+void orc_gen(uint64_t seed, uint64_t stream, uint64_t id, size_t len, char *out) {
+    const uint64_t key = splitmix64(splitmix64(seed) ^ (stream << 56) ^ id);
+    for (size_t pos = 0; pos < len; ++pos) out[pos] = "ACGT"[splitmix64(key + pos) >> 62];
+}
+
+#ifdef ORC_MAIN
+int main(int argc, char **argv) { return orc_hw2_main(argc, argv); }
+#endif
