@@ -1,0 +1,270 @@
+"""bioinformatics-algorithms_amd -- MI355X-native pairwise alignment (NW / SW, linear gap, int32).
+
+Python is only a thin ctypes binding over the C ABI of ``libpwalign.so`` (include/pwalign.h); all
+compute is in hand-written HIP kernels for gfx950.  There is NO CPU fallback: if the shared library
+is missing or no MI355X is visible, ``Context()`` raises.
+
+The directory name contains a hyphen, so import it through ``load()`` in ``_loader.py`` (or
+``importlib`` with ``spec_from_file_location``); tests/bench do exactly that.
+
+Mirror of the reference interface (Local_Global_Alignment/hw2.cpp):
+  ``Context.align('nw'|'sw', pattern, text, match, mismatch, gap)`` returns the five fields of the
+  reference's ``AlignmentResult`` (hw2.cpp:17-23) as a dict -- what
+  ``globalAlignmentNeedlemanWunsch`` (118) / ``localAlignmentSmithWaterman`` (192) return;
+  ``Context.scores(...)`` is the scores-only pass over the pair loop (328-338).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpwalign.so")
+CLI_PATH = os.path.join(_HERE, "host", "hw2_amd")
+
+MODE = {"nw": 0, "sw": 1, "global": 0, "local": 1}
+
+EXPORTS = [
+    "pwa_version", "pwa_strerror", "pwa_ctx_create", "pwa_ctx_destroy", "pwa_last_error", "pwa_scores",
+    "pwa_batch_create", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_fetch", "pwa_batch_info",
+    "pwa_batch_last_ms", "pwa_batch_destroy", "pwa_align", "pwa_align_last_stats", "pwa_align_batch",
+    "pwa_cigar_bound", "pwa_mdz_bound", "pwa_format_alignment",
+]
+
+
+class PwaError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libpwalign.so (built in-tree by __graft_entry__.build() / csrc/Makefile). Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PwaError("libpwalign.so is not built (%s); run `make -C bioinformatics-algorithms_amd/csrc`: "
+                       "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u8p, u32p, u64p, i32p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
+    L.pwa_version.restype = C.c_char_p
+    L.pwa_strerror.restype = C.c_char_p
+    L.pwa_strerror.argtypes = [C.c_int]
+    L.pwa_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.pwa_ctx_destroy.argtypes = [vp]
+    L.pwa_ctx_destroy.restype = None
+    L.pwa_last_error.argtypes = [vp]
+    L.pwa_last_error.restype = C.c_char_p
+    batch_in = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, u64p, C.c_uint32, u32p, u32p, C.c_uint64]
+    L.pwa_scores.argtypes = batch_in + [i32p, u32p, u32p]
+    L.pwa_batch_create.argtypes = batch_in + [C.c_int, C.POINTER(vp)]
+    L.pwa_batch_run.argtypes = [vp, vp]
+    L.pwa_batch_d_scores.argtypes = [vp]
+    L.pwa_batch_d_scores.restype = vp
+    L.pwa_batch_fetch.argtypes = [vp, i32p, u32p, u32p]
+    L.pwa_batch_info.argtypes = [vp, u64p, u64p, u64p, C.POINTER(C.c_char_p)]
+    L.pwa_batch_last_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.pwa_batch_destroy.argtypes = [vp]
+    L.pwa_batch_destroy.restype = None
+    L.pwa_align.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_uint64, vp, C.c_uint64, i32p, vp,
+                            C.c_uint64, u64p, u64p, u64p]
+    L.pwa_align_last_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), u64p]
+    L.pwa_align_batch.argtypes = batch_in + [i32p, vp, u64p, u64p, u64p, u64p]
+    L.pwa_cigar_bound.argtypes = [C.c_uint64]
+    L.pwa_cigar_bound.restype = C.c_uint64
+    L.pwa_mdz_bound.argtypes = [C.c_uint64]
+    L.pwa_mdz_bound.restype = C.c_uint64
+    L.pwa_format_alignment.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, vp, vp, i32p]
+    _lib = L
+    return L
+
+
+def _b(x):
+    return bytes(x) if isinstance(x, (bytes, bytearray, memoryview)) else x.encode("latin-1")
+
+
+def pack_sequences(seqs):
+    """list of bytes -> (concatenated bytes, uint64 offsets[n+1])"""
+    seqs = [_b(s) for s in seqs]
+    off = (C.c_uint64 * (len(seqs) + 1))()
+    tot = 0
+    for i, s in enumerate(seqs):
+        off[i] = tot
+        tot += len(s)
+    off[len(seqs)] = tot
+    return b"".join(seqs), off, seqs
+
+
+def format_alignment(pattern, text, ops, end):
+    """Host post-processing (hw2.cpp:59-116, 164-184, 267-278) through the C ABI."""
+    L = lib()
+    pattern, text, ops = _b(pattern), _b(text), _b(ops)
+    n_ops = len(ops)
+    ap = C.create_string_buffer(n_ops + 1)
+    ar = C.create_string_buffer(n_ops + 1)
+    cg = C.create_string_buffer(L.pwa_cigar_bound(n_ops))
+    md = C.create_string_buffer(L.pwa_mdz_bound(n_ops))
+    ov = C.c_int32(0)
+    endc = (C.c_uint64 * 2)(end[0], end[1])
+    rc = L.pwa_format_alignment(pattern, len(pattern), text, len(text), ops, n_ops, endc, ap, ar, cg, md, C.byref(ov))
+    if rc != 0:
+        raise PwaError("pwa_format_alignment: %s" % L.pwa_strerror(rc).decode())
+    return dict(aligned_pattern=ap.raw[:n_ops], aligned_reference=ar.raw[:n_ops], cigar=cg.value, mdz=md.value,
+                overlap=ov.value)
+
+
+class Context:
+    """One MI355X (HIP device ordinal)."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.pwa_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise PwaError("pwa_ctx_create(%d): %s -- the HIP path is required, there is no CPU fallback"
+                           % (device, self._L.pwa_strerror(rc).decode()))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pwa_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PwaError("%s: %s (%s)" % (what, self._L.pwa_strerror(rc).decode(),
+                                            self._L.pwa_last_error(self._h).decode()))
+
+    # -- scores-only pass (hw2.cpp:328-338, score field only)
+    def scores(self, mode, seqs, pair_a, pair_b, match, mismatch, gap, want_end=False):
+        blob, off, seqs = pack_sequences(seqs)
+        n = len(pair_a)
+        pa = (C.c_uint32 * max(n, 1))(*pair_a)
+        pb = (C.c_uint32 * max(n, 1))(*pair_b)
+        sc = (C.c_int32 * max(n, 1))()
+        ei = (C.c_uint32 * max(n, 1))() if want_end else None
+        ej = (C.c_uint32 * max(n, 1))() if want_end else None
+        rc = self._L.pwa_scores(self._h, MODE[mode], match, mismatch, gap, blob, off, len(seqs), pa, pb, n, sc, ei, ej)
+        self._check(rc, "pwa_scores")
+        if want_end:
+            return list(sc[:n]), list(ei[:n]), list(ej[:n])
+        return list(sc[:n])
+
+    def batch(self, mode, seqs, pair_a, pair_b, match, mismatch, gap, want_end=False):
+        return Batch(self, mode, seqs, pair_a, pair_b, match, mismatch, gap, want_end)
+
+    # -- one full alignment = one call of hw2.cpp:118 / 192
+    def align(self, mode, pattern, text, match, mismatch, gap, raw=False):
+        pattern, text = _b(pattern), _b(text)
+        n, m = len(pattern), len(text)
+        ops = C.create_string_buffer(n + m + 1)
+        score = C.c_int32(0)
+        n_ops = C.c_uint64(0)
+        end = (C.c_uint64 * 2)()
+        start = (C.c_uint64 * 2)()
+        rc = self._L.pwa_align(self._h, MODE[mode], match, mismatch, gap, pattern, n, text, m, C.byref(score), ops,
+                               n + m, C.byref(n_ops), end, start)
+        self._check(rc, "pwa_align")
+        out = dict(score=score.value, ops=ops.raw[:n_ops.value], end=(end[0], end[1]), start=(start[0], start[1]))
+        if not raw:
+            out.update(format_alignment(pattern, text, out["ops"], out["end"]))
+        return out
+
+    def align_batch(self, mode, seqs, pair_a, pair_b, match, mismatch, gap):
+        blob, off, seqs = pack_sequences(seqs)
+        n = len(pair_a)
+        pa = (C.c_uint32 * max(n, 1))(*pair_a)
+        pb = (C.c_uint32 * max(n, 1))(*pair_b)
+        ooff = (C.c_uint64 * max(n, 1))()
+        tot = 0
+        for k in range(n):
+            ooff[k] = tot
+            tot += len(seqs[pair_a[k]]) + len(seqs[pair_b[k]])
+        ops = C.create_string_buffer(tot + 1)
+        sc = (C.c_int32 * max(n, 1))()
+        nops = (C.c_uint64 * max(n, 1))()
+        endc = (C.c_uint64 * (2 * max(n, 1)))()
+        startc = (C.c_uint64 * (2 * max(n, 1)))()
+        rc = self._L.pwa_align_batch(self._h, MODE[mode], match, mismatch, gap, blob, off, len(seqs), pa, pb, n, sc, ops,
+                                     ooff, nops, endc, startc)
+        self._check(rc, "pwa_align_batch")
+        res = []
+        for k in range(n):
+            o = ops.raw[ooff[k]:ooff[k] + nops[k]]
+            res.append(dict(score=sc[k], ops=o, end=(endc[2 * k], endc[2 * k + 1]),
+                            start=(startc[2 * k], startc[2 * k + 1])))
+        return res
+
+    def align_stats(self):
+        f, t, b = C.c_float(0), C.c_float(0), C.c_uint64(0)
+        self._L.pwa_align_last_stats(self._h, C.byref(f), C.byref(t), C.byref(b))
+        return dict(fill_ms=f.value, traceback_ms=t.value, band_bytes=b.value)
+
+
+class Batch:
+    """Prepared scores-only batch: inputs resident in HBM, run() only enqueues kernels."""
+
+    def __init__(self, ctx, mode, seqs, pair_a, pair_b, match, mismatch, gap, want_end=False):
+        self._ctx, self._L = ctx, ctx._L
+        blob, off, seqs = pack_sequences(seqs)
+        self.n_pairs = len(pair_a)
+        n = self.n_pairs
+        if hasattr(pair_a, "ctypes"):   # numpy uint32 arrays
+            pa = pair_a.ctypes.data_as(C.POINTER(C.c_uint32))
+            pb = pair_b.ctypes.data_as(C.POINTER(C.c_uint32))
+            self._keep = (pair_a, pair_b)
+        else:
+            pa = (C.c_uint32 * max(n, 1))(*pair_a)
+            pb = (C.c_uint32 * max(n, 1))(*pair_b)
+        h = C.c_void_p()
+        rc = self._L.pwa_batch_create(ctx._h, MODE[mode], match, mismatch, gap, blob, off, len(seqs), pa, pb, n,
+                                      1 if want_end else 0, C.byref(h))
+        ctx._check(rc, "pwa_batch_create")
+        self._h = h
+        self.want_end = want_end
+
+    def run(self, stream=None):
+        self._ctx._check(self._L.pwa_batch_run(self._h, stream), "pwa_batch_run")
+
+    def d_scores(self):
+        return self._L.pwa_batch_d_scores(self._h)
+
+    def last_ms(self):
+        ms = C.c_float(0)
+        self._ctx._check(self._L.pwa_batch_last_ms(self._h, C.byref(ms)), "pwa_batch_last_ms")
+        return ms.value
+
+    def info(self):
+        cells, padded, nt = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        name = C.c_char_p()
+        self._L.pwa_batch_info(self._h, C.byref(cells), C.byref(padded), C.byref(nt), C.byref(name))
+        return dict(cells=cells.value, padded_cells=padded.value, n_tasks=nt.value, kernel=name.value.decode())
+
+    def fetch(self, numpy_out=False):
+        n = self.n_pairs
+        sc = (C.c_int32 * max(n, 1))()
+        ei = (C.c_uint32 * max(n, 1))() if self.want_end else None
+        ej = (C.c_uint32 * max(n, 1))() if self.want_end else None
+        self._ctx._check(self._L.pwa_batch_fetch(self._h, sc, ei, ej), "pwa_batch_fetch")
+        if numpy_out:
+            import numpy as np
+            s = np.ctypeslib.as_array(sc)[:n].copy()
+            return (s, np.ctypeslib.as_array(ei)[:n].copy(), np.ctypeslib.as_array(ej)[:n].copy()) if self.want_end else s
+        if self.want_end:
+            return list(sc[:n]), list(ei[:n]), list(ej[:n])
+        return list(sc[:n])
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pwa_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close

@@ -1,0 +1,230 @@
+// batch_scores.hip.h -- scores-only DP for MANY pairs (gfx950 / MI355X).
+//
+// Replaces the score part of hw2.cpp's per-pair calls in the loop 328-338:
+//   NW  dp[n][m]           recurrence hw2.cpp:138-156
+//   SW  max over all cells recurrence hw2.cpp:205-231
+//
+// Mapping (MI355X-first, nothing like the reference's row-major scalar loop):
+//   * one 64-lane wavefront = one "wave task" = up to 64 PATTERNS against ONE shared TEXT;
+//     lane l owns the whole DP matrix of pair (pattern_l, text): no cross-lane traffic at all;
+//   * the text character of a column is wave-uniform, so it lives in an SGPR (scalar loads);
+//   * each lane keeps a register tile of R consecutive DP rows ("strip"): H[R] int32 in VGPRs plus
+//     the strip's R pattern symbols packed 4 per VGPR; a column update is R dependent-free
+//     register cells; columns are processed 4 at a time in a skewed (anti-diagonal) order so
+//     that four independent dependency chains are in flight per lane;
+//   * patterns longer than R rows take several strips; the strip's bottom row is handed to the
+//     next strip through a per-workgroup HBM row buffer laid out [column/4][lane][4] so that every
+//     access is one coalesced 1 KiB dwordx4 wave access (8 B per R cells per lane).  The column
+//     loop is kept ONE basic block: the row load/store is unconditional and a stride of 0 parks
+//     it on a 1 KiB dummy block when there is no strip above / below (a uniform branch in that
+//     loop makes hipcc double the live H registers and spill);
+//   * substitution score of 4 rows at once: one v_xor + one v_perm_b32 byte-table lookup
+//     (alphabets of <= 7 symbols, scores in int8), then one SDWA add per cell; the generic
+//     raw-byte path does compare + select per cell;
+//   * wave tasks are pulled from an atomic queue (heterogeneous task sizes).
+//
+// Integer recurrences only: VALU-issue bound, no MFMA, HBM traffic ~1e-5 B/cell (C3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pwa {
+
+enum { BM_SW = 0, BM_NW = 1, BM_NWG = 2 };   // NWG: NW in gap-shifted space G = H - g(i+j)
+enum { SC_PERM = 0, SC_CMP = 1 };
+
+struct BatchTask {
+    uint32_t text_off;   // byte offset of the text symbols in the arena (16-byte aligned)
+    uint32_t text_len;   // m
+    uint32_t slot0;      // first of this task's 64 lane slots
+    uint32_t n_strips;   // ceil(longest pattern of the task / R)
+};
+
+struct BatchParams {
+    const uint8_t* arena;        // symbols of every sequence, each 16-byte aligned, with slack
+    const BatchTask* tasks;
+    const uint32_t* slot_poff;   // per slot: arena offset of the pattern
+    const uint32_t* slot_plen;   // per slot: pattern length, 0 = empty lane
+    const uint32_t* slot_out;    // per slot: index into scores
+    int32_t* scores;
+    int32_t* hand;               // strip hand-off rows, one region per workgroup
+    uint64_t hand_stride;        // int32 elements per workgroup region (2 halves)
+    uint32_t hand_half;          // int32 elements per half
+    uint32_t* queue;             // atomic task counter (zeroed before every launch)
+    uint32_t n_tasks;
+    int32_t match, mismatch, gap;
+    uint32_t tab_hi, tab_lo;     // SC_PERM: byte table, selector 0 -> match, 1..7 -> mismatch
+    uint32_t pad_word;           // symbol that matches nothing in any text, x4
+};
+
+__device__ __forceinline__ int addw(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__device__ __forceinline__ int mulw(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+
+// One block of C columns over the lane's R-row register strip.
+//   H[r]     in:  dp[row0+r+1][j0]        (the column left of the block)
+//            out: dp[row0+r+1][j0+C]
+//   top[k]   dp[row0][j0+1+k]  (row above the strip), topprev = dp[row0][j0]
+//   bot[k]   dp[row0+R][j0+1+k]
+template <int R, int C, int MODE, int SCORE>
+__device__ __forceinline__ void dp_block(int (&H)[R], const uint32_t (&pk)[R / 4], const uint32_t (&cs)[C],
+                                         const int (&top)[C], int& topprev, int (&bot)[C], int& best,
+                                         const BatchParams& P) {
+    constexpr int Q = R / 4;
+    int d[C], u[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        d[k] = (k == 0) ? topprev : top[k - 1];
+        u[k] = top[k];
+    }
+    topprev = top[C - 1];
+    const int gap = P.gap;
+    // skewed order: column k runs one quad (4 rows) behind column k-1
+#pragma unroll
+    for (int step = 0; step < Q + C - 1; ++step) {
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int q = step - k;
+            if (q >= 0 && q < Q) {
+                uint32_t s4 = 0;
+                if (SCORE == SC_PERM) s4 = __builtin_amdgcn_perm(P.tab_hi, P.tab_lo, pk[q] ^ cs[k]);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int r = 4 * q + b;
+                    int s;
+                    if (SCORE == SC_PERM) s = (int)(int8_t)(s4 >> (8 * b));
+                    else s = (((pk[q] >> (8 * b)) & 0xffu) == cs[k]) ? P.match : P.mismatch;
+                    const int t = addw(d[k], s);   // diagonal candidate, hw2.cpp:142 / 208
+                    const int l = H[r];            // dp[i][j-1]
+                    d[k] = l;
+                    int h;
+                    if (MODE == BM_SW) {
+                        const int e = addw(max(u[k], l), gap);   // hw2.cpp:209-210
+                        h = max(max(t, e), 0);                   // hw2.cpp:211
+                        best = max(best, h);                     // hw2.cpp:225 (value only)
+                    } else if (MODE == BM_NW) {
+                        const int e = addw(max(u[k], l), gap);   // hw2.cpp:140-141
+                        h = max(t, e);                           // hw2.cpp:142-153 (value only)
+                    } else {
+                        h = max(max(t, u[k]), l);                // gap folded into the coordinates
+                    }
+                    H[r] = h;
+                    u[k] = h;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < C; ++k) bot[k] = u[k];
+}
+
+template <int R, int MODE, int SCORE>
+__global__ __launch_bounds__(64) void batch_scores_kernel(const BatchParams P) {
+    constexpr int Q = R / 4;
+    const int lane = threadIdx.x;
+    int32_t* const hand = P.hand + (size_t)blockIdx.x * P.hand_stride;
+
+    for (;;) {
+        uint32_t tid = 0;
+        if (lane == 0) tid = atomicAdd(P.queue, 1u);
+        tid = __builtin_amdgcn_readfirstlane(tid);
+        if (tid >= P.n_tasks) break;
+
+        const BatchTask task = P.tasks[tid];
+        const int m = (int)task.text_len;
+        const uint32_t* tx = reinterpret_cast<const uint32_t*>(P.arena + task.text_off);
+        const uint32_t slot = task.slot0 + lane;
+        const uint32_t poff = P.slot_poff[slot];
+        const int n = (int)P.slot_plen[slot];
+        const uint32_t outi = P.slot_out[slot];
+        const int nblk = m >> 2, rem = m & 3;
+
+        int best = 0;
+        int nw_score = 0;
+
+        for (int s = 0; s < (int)task.n_strips; ++s) {
+            const int row0 = s * R;
+            // ---- this strip's pattern symbols, padded past the pattern's end
+            uint32_t pk[Q];
+            {
+                const uint32_t* pp = reinterpret_cast<const uint32_t*>(P.arena + poff + row0);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const int valid = n - (row0 + 4 * q);   // symbols of this dword inside the pattern
+                    uint32_t w = pp[q];
+                    const uint32_t keep = valid >= 4 ? 0xffffffffu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
+                    pk[q] = (w & keep) | (P.pad_word & ~keep);
+                }
+            }
+            // ---- column 0 of the strip (hw2.cpp:125-130; SW: zeros, 193)
+            int H[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) H[r] = (MODE == BM_NW) ? mulw(row0 + r + 1, P.gap) : 0;
+            int topprev = (MODE == BM_NW) ? mulw(row0, P.gap) : 0;
+
+            const int32_t* hin = hand + (size_t)((s + 1) & 1) * P.hand_half;   // written by strip s-1
+            int32_t* hout = hand + (size_t)(s & 1) * P.hand_half;
+            const bool has_top = s > 0;
+            const bool has_bot = s + 1 < (int)task.n_strips;
+
+            const size_t in_stride = has_top ? 64 : 0, out_stride = has_bot ? 64 : 0;
+            const int4* hin4 = reinterpret_cast<const int4*>(hin) + lane;
+            int4* hout4 = reinterpret_cast<int4*>(hout) + lane;
+            int4 tnext = hin4[0];
+            uint32_t cwn = tx[0];
+            for (int jb = 0; jb < nblk; ++jb) {
+                const uint32_t cw = cwn;
+                const int4 tcur = tnext;
+                cwn = tx[jb + 1];   // arena slack makes the over-read safe
+                tnext = hin4[(size_t)(jb + 1) * in_stride];
+                int top[4], bot[4];
+                uint32_t cs[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t c = (cw >> (8 * k)) & 0xffu;
+                    cs[k] = (SCORE == SC_PERM) ? c * 0x01010101u : c;
+                }
+                {
+                    const int tl[4] = {tcur.x, tcur.y, tcur.z, tcur.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) top[k] = has_top ? tl[k] : ((MODE == BM_NW) ? mulw(4 * jb + k + 1, P.gap) : 0);   // hw2.cpp:131-136
+                }
+                dp_block<R, 4, MODE, SCORE>(H, pk, cs, top, topprev, bot, best, P);
+                hout4[(size_t)jb * out_stride] = make_int4(bot[0], bot[1], bot[2], bot[3]);
+            }
+            if (rem > 0) {
+                uint32_t cw = cwn;
+                int t0 = tnext.x, t1 = tnext.y, t2 = tnext.z;
+#pragma unroll 1
+                for (int k = 0; k < rem; ++k) {
+                    const uint32_t c = cw & 0xffu;
+                    cw >>= 8;
+                    const uint32_t cs1[1] = {(SCORE == SC_PERM) ? c * 0x01010101u : c};
+                    const int top1[1] = {has_top ? t0 : ((MODE == BM_NW) ? mulw(4 * nblk + k + 1, P.gap) : 0)};
+                    t0 = t1;
+                    t1 = t2;
+                    int bot1[1];
+                    dp_block<R, 1, MODE, SCORE>(H, pk, cs1, top1, topprev, bot1, best, P);
+                    hout[((size_t)nblk * out_stride + lane) * 4 + k] = bot1[0];
+                }
+            }
+            // ---- NW: dp[n][m] sits in this strip for the lanes whose pattern ends here (hw2.cpp:186)
+            if (MODE != BM_SW) {
+                const int rl = n - 1 - row0;
+                if (rl >= 0 && rl < R) {
+                    int v = 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) v = (rl == r) ? H[r] : v;
+                    nw_score = v;
+                }
+            }
+        }
+        if (outi != 0xffffffffu) {
+            int sc = best;
+            if (MODE == BM_NW) sc = nw_score;
+            if (MODE == BM_NWG) sc = addw(nw_score, mulw(n + m, P.gap));
+            P.scores[outi] = sc;
+        }
+    }
+}
+
+}  // namespace pwa

@@ -1,0 +1,751 @@
+// pwalign.hip -- the C ABI of include/pwalign.h: contexts, the host-side wave-task scheduler,
+// device memory management and kernel launches.  gfx950 only; there is no CPU path.
+#include "../../include/pwalign.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "batch_scores.hip.h"
+#include "pair_fill.hip.h"
+
+using namespace pwa;
+
+// ------------------------------------------------------------------------------------ context
+struct pwa_ctx {
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    std::string err;
+    float fill_ms = 0.f, tb_ms = 0.f;
+    uint64_t band_bytes = 0;
+};
+
+namespace {
+
+struct DevBuf {   // RAII device allocation
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        else p = nullptr;
+        return e;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+int fail(pwa_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPC(ctx, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            return fail((ctx), e_ == hipErrorOutOfMemory ? PWA_E_NOMEM : PWA_E_HIP,                  \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                          \
+        }                                                                                            \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline int32_t wrap_mul(int64_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+
+// --------------------------------------------------------------------------- kernel tables
+typedef void (*batch_kernel_t)(const BatchParams);
+struct BatchKernelEntry {
+    int R, mode, score;
+    batch_kernel_t fn;
+    const char* name;
+};
+#define BK(R, M, S) {R, M, S, batch_scores_kernel<R, M, S>, "batch_scores_kernel<R=" #R "," #M "," #S ">"}
+const BatchKernelEntry kBatchKernels[] = {
+    BK(64, BM_SW, SC_PERM),   BK(128, BM_SW, SC_PERM),  BK(152, BM_SW, SC_PERM),
+    BK(64, BM_SW, SC_CMP),    BK(128, BM_SW, SC_CMP),   BK(152, BM_SW, SC_CMP),
+    BK(64, BM_NW, SC_PERM),   BK(128, BM_NW, SC_PERM),  BK(152, BM_NW, SC_PERM),
+    BK(64, BM_NW, SC_CMP),    BK(128, BM_NW, SC_CMP),   BK(152, BM_NW, SC_CMP),
+    BK(64, BM_NWG, SC_PERM),  BK(128, BM_NWG, SC_PERM), BK(152, BM_NWG, SC_PERM),
+    BK(64, BM_NWG, SC_CMP),   BK(128, BM_NWG, SC_CMP),  BK(152, BM_NWG, SC_CMP),
+};
+#undef BK
+const int kStripRows[] = {64, 128, 152};
+
+const BatchKernelEntry* find_batch_kernel(int R, int mode, int score) {
+    for (const auto& e : kBatchKernels)
+        if (e.R == R && e.mode == mode && e.score == score) return &e;
+    return nullptr;
+}
+
+constexpr int kRL = 4;   // rows per lane of the wavefront (pair) engine
+
+typedef void (*pair_kernel_t)(const PairParams);
+pair_kernel_t pair_fill_fn(bool local, bool tb, bool sband) {
+    if (local) {
+        if (tb) return sband ? pair_fill_kernel<kRL, true, true, true> : pair_fill_kernel<kRL, true, true, false>;
+        return pair_fill_kernel<kRL, true, false, false>;
+    }
+    if (tb) return sband ? pair_fill_kernel<kRL, false, true, true> : pair_fill_kernel<kRL, false, true, false>;
+    return pair_fill_kernel<kRL, false, false, false>;
+}
+pair_kernel_t pair_tb_fn(bool local) {
+    return local ? pair_traceback_kernel<kRL, true> : pair_traceback_kernel<kRL, false>;
+}
+
+size_t tb_band_bytes(uint64_t n, uint64_t m) {
+    const uint64_t stripes = (n + 64 * kRL - 1) / (64 * kRL);
+    return (size_t)(stripes * (m + 63) * 64 * kRL);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ batch
+struct pwa_batch {
+    pwa_ctx* ctx = nullptr;
+    int mode = 0;
+    uint64_t n_pairs = 0;
+    uint64_t cells = 0, padded_cells = 0;
+    bool want_end = false;
+    // engine 1: register-strip kernels
+    bool use_strips = false;
+    const BatchKernelEntry* kern = nullptr;
+    BatchParams bp{};
+    uint32_t grid = 0;
+    DevBuf arena, tasks, slot_poff, slot_plen, slot_out, hand, queue, scores;
+    // engine 2: wavefront kernels without traceback band (exact end cells, any scoring)
+    PairParams pp{};
+    DevBuf pair_desc, pair_res, rowbuf;
+    uint32_t pair_grid = 0;
+    uint64_t n_live = 0;            // pairs that reach a kernel (n > 0 and m > 0)
+    std::vector<uint32_t> live_idx; // engine 2: pair index of descriptor k
+    std::vector<int32_t> host_scores;   // trivial pairs resolved on the host
+    std::vector<uint32_t> host_end_i, host_end_j;
+    std::string kernel_name;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ran = false;
+};
+
+extern "C" {
+
+const char* pwa_version(void) { return "pwalign 0.1 gfx950"; }
+
+const char* pwa_strerror(int code) {
+    switch (code) {
+        case PWA_OK: return "ok";
+        case PWA_E_INVALID: return "invalid argument";
+        case PWA_E_NODEVICE: return "no usable gfx950 device";
+        case PWA_E_HIP: return "HIP runtime error";
+        case PWA_E_NOMEM: return "out of memory";
+        case PWA_E_CAPACITY: return "capacity exceeded";
+        default: return "unknown error";
+    }
+}
+
+int pwa_ctx_create(int device, pwa_ctx** out) {
+    if (!out) return PWA_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PWA_E_NODEVICE;
+    if (device < 0 || device >= count) return PWA_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return PWA_E_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return PWA_E_NODEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PWA_E_NODEVICE;   // kernels exist for gfx950 only
+    pwa_ctx* c = new (std::nothrow) pwa_ctx();
+    if (!c) return PWA_E_NOMEM;
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return PWA_E_HIP;
+    }
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            pwa_ctx_destroy(c);
+            return PWA_E_HIP;
+        }
+    *out = c;
+    return PWA_OK;
+}
+
+void pwa_ctx_destroy(pwa_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* pwa_last_error(const pwa_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+// ---------------------------------------------------------------------------- batch: create
+int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* seq_bytes,
+                     const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
+                     uint64_t n_pairs, int want_end_cells, pwa_batch** out) {
+    if (!ctx || !out) return PWA_E_INVALID;
+    *out = nullptr;
+    if (mode != PWA_MODE_NW && mode != PWA_MODE_SW) return fail(ctx, PWA_E_INVALID, "unknown mode");
+    if (!seq_off || (n_pairs && (!pair_a || !pair_b))) return fail(ctx, PWA_E_INVALID, "null input");
+    if (n_seq && !seq_bytes && seq_off[n_seq] != 0) return fail(ctx, PWA_E_INVALID, "null seq_bytes");
+    if (n_pairs >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "more than 2^32-2 pairs in one batch");
+    for (uint32_t s = 0; s < n_seq; ++s)
+        if (seq_off[s + 1] < seq_off[s]) return fail(ctx, PWA_E_INVALID, "seq_off not monotone");
+    for (uint64_t k = 0; k < n_pairs; ++k)
+        if (pair_a[k] >= n_seq || pair_b[k] >= n_seq) return fail(ctx, PWA_E_INVALID, "pair index out of range");
+    HIPC(ctx, hipSetDevice(ctx->device));
+
+    pwa_batch* b = new (std::nothrow) pwa_batch();
+    if (!b) return fail(ctx, PWA_E_NOMEM, "host allocation");
+    struct Guard {
+        pwa_batch* b;
+        ~Guard() { if (b) pwa_batch_destroy(b); }
+    } guard{b};
+    b->ctx = ctx;
+    b->mode = mode;
+    b->n_pairs = n_pairs;
+    b->want_end = want_end_cells != 0;
+    const bool local = mode == PWA_MODE_SW;
+
+    auto slen = [&](uint32_t s) -> uint64_t { return seq_off[s + 1] - seq_off[s]; };
+
+    // ---- pairs with an empty side never reach a kernel (hw2.cpp: loops 138/205 do not run)
+    b->host_scores.assign(n_pairs, 0);
+    if (b->want_end) {
+        b->host_end_i.assign(n_pairs, 0);
+        b->host_end_j.assign(n_pairs, 0);
+    }
+    std::vector<uint32_t> live;
+    live.reserve(n_pairs);
+    uint64_t max_n = 0, max_m = 0;
+    for (uint64_t k = 0; k < n_pairs; ++k) {
+        const uint64_t n = slen(pair_a[k]), m = slen(pair_b[k]);
+        if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
+        if (n == 0 || m == 0) {
+            if (!local) b->host_scores[k] = wrap_mul((int64_t)(n + m), gap);   // dp[n][0] / dp[0][m], hw2.cpp:125-136
+            if (b->want_end && !local) {
+                b->host_end_i[k] = (uint32_t)n;
+                b->host_end_j[k] = (uint32_t)m;
+            }
+            continue;
+        }
+        live.push_back((uint32_t)k);
+        b->cells += n * m;
+        max_n = std::max(max_n, n);
+        max_m = std::max(max_m, m);
+    }
+    b->n_live = live.size();
+
+    HIPC(ctx, b->scores.alloc(std::max<uint64_t>(n_pairs, 1) * sizeof(int32_t)));
+    HIPC(ctx, hipMemcpy(b->scores.p, b->host_scores.data(), n_pairs * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPC(ctx, b->queue.alloc(64));
+    HIPC(ctx, hipEventCreate(&b->ev0));
+    HIPC(ctx, hipEventCreate(&b->ev1));
+    if (live.empty()) {
+        b->kernel_name = "none";
+        guard.b = nullptr;
+        *out = b;
+        return PWA_OK;
+    }
+
+    // ---- which sequences play which role; text alphabet
+    std::vector<uint8_t> is_text(n_seq, 0), is_used(n_seq, 0);
+    for (uint32_t k : live) {
+        is_text[pair_b[k]] = 1;
+        is_used[pair_a[k]] = is_used[pair_b[k]] = 1;
+    }
+    bool present[256] = {false};
+    for (uint32_t s = 0; s < n_seq; ++s)
+        if (is_text[s])
+            for (uint64_t o = seq_off[s]; o < seq_off[s + 1]; ++o) present[seq_bytes[o]] = true;
+    int n_alpha = 0;
+    int code_of[256];
+    int absent_byte = -1;
+    for (int v = 0; v < 256; ++v) {
+        if (present[v]) code_of[v] = n_alpha++;
+        else {
+            code_of[v] = -1;
+            if (absent_byte < 0) absent_byte = v;
+        }
+    }
+
+    // ---- engine choice.  The strip engine pads short patterns with rows that match nothing; for SW
+    // those rows can only hold values <= real rows if mismatch <= 0 and gap <= 0.
+    const bool strips_ok = !b->want_end && (!local || (mismatch <= 0 && gap <= 0));
+    auto fits8 = [](int v) { return v >= -128 && v <= 127; };
+    b->use_strips = strips_ok;
+
+    // ---- device arena: every used sequence, 16-byte aligned, as symbols of the chosen coding
+    int score_path = SC_CMP;
+    int kmode = local ? BM_SW : BM_NW;
+    int tab_match = match, tab_mismatch = mismatch;
+    if (b->use_strips) {
+        if (!local) {
+            // gap-shifted NW: G = H - g(i+j) needs every |value| to stay far inside int32
+            const int64_t amax = std::max<int64_t>({std::llabs((long long)match), std::llabs((long long)mismatch),
+                                                    std::llabs((long long)gap)});
+            const int64_t s_match = (int64_t)match - 2 * (int64_t)gap, s_mis = (int64_t)mismatch - 2 * (int64_t)gap;
+            if ((int64_t)(max_n + max_m + 4) * amax * 4 < (1ll << 30) && fits8((int)s_match) && fits8((int)s_mis)) {
+                kmode = BM_NWG;
+                tab_match = (int)s_match;
+                tab_mismatch = (int)s_mis;
+            }
+        }
+        if (n_alpha <= 7 && fits8(tab_match) && fits8(tab_mismatch)) score_path = SC_PERM;
+        else if (kmode == BM_NWG && n_alpha > 7) { /* compare path works in G space too */ }
+        if (score_path == SC_CMP && absent_byte < 0) b->use_strips = false;   // no byte left to pad with
+    }
+
+    std::vector<uint64_t> aoff(n_seq, 0);
+    uint64_t arena_bytes = 0;
+    for (uint32_t s = 0; s < n_seq; ++s)
+        if (is_used[s]) {
+            aoff[s] = arena_bytes;
+            arena_bytes += align_up(slen(s) + 1, 16);
+        }
+    arena_bytes += 512;   // slack: strips and text words are over-read, never over-used
+    if (arena_bytes >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "sequence arena exceeds 4 GiB");
+    {
+        std::vector<uint8_t> host_arena(arena_bytes, 0);
+        const bool coded = b->use_strips && score_path == SC_PERM;
+        for (uint32_t s = 0; s < n_seq; ++s)
+            if (is_used[s]) {
+                uint8_t* dst = host_arena.data() + aoff[s];
+                const uint8_t* src = seq_bytes + seq_off[s];
+                const uint64_t len = slen(s);
+                if (coded)
+                    for (uint64_t o = 0; o < len; ++o) dst[o] = (uint8_t)(code_of[src[o]] >= 0 ? code_of[src[o]] : 7);
+                else
+                    std::memcpy(dst, src, len);
+            }
+        HIPC(ctx, b->arena.alloc(arena_bytes));
+        HIPC(ctx, hipMemcpy(b->arena.p, host_arena.data(), arena_bytes, hipMemcpyHostToDevice));
+    }
+
+    if (b->use_strips) {
+        // ---- wave tasks: pairs grouped by text, patterns sorted by length, 64 per wave
+        std::vector<uint32_t> order(live);
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+            if (pair_b[x] != pair_b[y]) return pair_b[x] < pair_b[y];
+            const uint64_t lx = slen(pair_a[x]), ly = slen(pair_a[y]);
+            if (lx != ly) return lx > ly;
+            return x < y;
+        });
+        struct HostTask {
+            uint32_t text, first, count;
+            uint64_t maxlen;
+        };
+        std::vector<HostTask> ht;
+        for (size_t p = 0; p < order.size();) {
+            size_t q = p;
+            while (q < order.size() && q - p < 64 && pair_b[order[q]] == pair_b[order[p]]) ++q;
+            ht.push_back({pair_b[order[p]], (uint32_t)p, (uint32_t)(q - p), slen(pair_a[order[p]])});
+            p = q;
+        }
+        // ---- strip height: least padded work, ties to the taller strip
+        int bestR = kStripRows[0];
+        long double best_cost = -1;
+        for (int R : kStripRows) {
+            long double cost = 0;
+            for (const auto& t : ht) cost += (long double)((t.maxlen + R - 1) / R * R) * (long double)slen(t.text) * 64.0L;
+            if (best_cost < 0 || cost <= best_cost) {
+                best_cost = cost;
+                bestR = R;
+            }
+        }
+        const int R = bestR;
+        b->padded_cells = (uint64_t)best_cost;
+        b->kern = find_batch_kernel(R, kmode, score_path);
+        if (!b->kern) return fail(ctx, PWA_E_INVALID, "internal: no kernel instantiation");
+        b->kernel_name = b->kern->name;
+
+        std::sort(ht.begin(), ht.end(), [&](const HostTask& x, const HostTask& y) {   // longest first
+            const uint64_t cx = (x.maxlen + R - 1) / R * slen(x.text), cy = (y.maxlen + R - 1) / R * slen(y.text);
+            if (cx != cy) return cx > cy;
+            return x.first < y.first;
+        });
+        const size_t nt = ht.size();
+        std::vector<BatchTask> tasks(nt);
+        std::vector<uint32_t> spoff(nt * 64, 0), splen(nt * 64, 0), sout(nt * 64, 0xffffffffu);
+        uint32_t max_strips = 1;
+        for (size_t t = 0; t < nt; ++t) {
+            tasks[t].text_off = (uint32_t)aoff[ht[t].text];
+            tasks[t].text_len = (uint32_t)slen(ht[t].text);
+            tasks[t].slot0 = (uint32_t)(t * 64);
+            tasks[t].n_strips = (uint32_t)((ht[t].maxlen + R - 1) / R);
+            max_strips = std::max(max_strips, tasks[t].n_strips);
+            for (uint32_t l = 0; l < ht[t].count; ++l) {
+                const uint32_t k = order[ht[t].first + l];
+                spoff[t * 64 + l] = (uint32_t)aoff[pair_a[k]];
+                splen[t * 64 + l] = (uint32_t)slen(pair_a[k]);
+                sout[t * 64 + l] = k;
+            }
+        }
+        HIPC(ctx, b->tasks.alloc(nt * sizeof(BatchTask)));
+        HIPC(ctx, hipMemcpy(b->tasks.p, tasks.data(), nt * sizeof(BatchTask), hipMemcpyHostToDevice));
+        HIPC(ctx, b->slot_poff.alloc(nt * 64 * 4));
+        HIPC(ctx, hipMemcpy(b->slot_poff.p, spoff.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+        HIPC(ctx, b->slot_plen.alloc(nt * 64 * 4));
+        HIPC(ctx, hipMemcpy(b->slot_plen.p, splen.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+        HIPC(ctx, b->slot_out.alloc(nt * 64 * 4));
+        HIPC(ctx, hipMemcpy(b->slot_out.p, sout.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+
+        int per_cu = 0;
+        HIPC(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(b->kern->fn), 64, 0));
+        per_cu = std::max(1, std::min(per_cu, 32));
+        b->grid = (uint32_t)std::min<uint64_t>(nt, (uint64_t)ctx->num_cu * per_cu);
+        const uint64_t half = (max_strips > 1) ? ((max_m + 3) / 4 + 1) * 256 : 256;   // int32 per half
+        HIPC(ctx, b->hand.alloc((size_t)b->grid * 2 * half * sizeof(int32_t)));
+
+        BatchParams& P = b->bp;
+        P.arena = b->arena.as<uint8_t>();
+        P.tasks = b->tasks.as<BatchTask>();
+        P.slot_poff = b->slot_poff.as<uint32_t>();
+        P.slot_plen = b->slot_plen.as<uint32_t>();
+        P.slot_out = b->slot_out.as<uint32_t>();
+        P.scores = b->scores.as<int32_t>();
+        P.hand = b->hand.as<int32_t>();
+        P.hand_stride = 2 * half;
+        P.hand_half = (uint32_t)half;
+        P.queue = b->queue.as<uint32_t>();
+        P.n_tasks = (uint32_t)nt;
+        P.match = tab_match;
+        P.mismatch = tab_mismatch;
+        P.gap = gap;
+        const uint32_t bm = (uint8_t)(int8_t)tab_match, bx = (uint8_t)(int8_t)tab_mismatch;
+        P.tab_lo = bm | (bx << 8) | (bx << 16) | (bx << 24);   // selector 0 -> match
+        P.tab_hi = bx * 0x01010101u;                           // selectors 4..7 -> mismatch
+        const uint32_t pad = (score_path == SC_PERM) ? 7u : (uint32_t)absent_byte;
+        P.pad_word = pad * 0x01010101u;
+    } else {
+        // ---- wavefront engine, no traceback band: exact first-maximum end cells, any scoring
+        const size_t nl = live.size();
+        b->live_idx = live;
+        b->padded_cells = 0;
+        std::vector<PairDesc> pd(nl);
+        HIPC(ctx, b->pair_res.alloc(nl * sizeof(PairResult)));
+        HIPC(ctx, hipMemset(b->pair_res.p, 0, nl * sizeof(PairResult)));
+        for (size_t q = 0; q < nl; ++q) {
+            const uint32_t k = live[q];
+            std::memset(&pd[q], 0, sizeof(PairDesc));
+            pd[q].pat = b->arena.as<uint8_t>() + aoff[pair_a[k]];
+            pd[q].txt = b->arena.as<uint8_t>() + aoff[pair_b[k]];
+            pd[q].n = (int32_t)slen(pair_a[k]);
+            pd[q].m = (int32_t)slen(pair_b[k]);
+            pd[q].res = b->pair_res.as<PairResult>() + q;
+            const uint64_t n = slen(pair_a[k]), m = slen(pair_b[k]);
+            b->padded_cells += (n + 64 * kRL - 1) / (64 * kRL) * (64 * kRL) * m;
+        }
+        HIPC(ctx, b->pair_desc.alloc(nl * sizeof(PairDesc)));
+        HIPC(ctx, hipMemcpy(b->pair_desc.p, pd.data(), nl * sizeof(PairDesc), hipMemcpyHostToDevice));
+        b->pair_grid = (uint32_t)std::min<uint64_t>(nl, (uint64_t)ctx->num_cu * 16);
+        const uint64_t stride = align_up(max_m + 64, 64);
+        HIPC(ctx, b->rowbuf.alloc((size_t)b->pair_grid * 2 * stride * sizeof(int32_t)));
+        b->pp.pairs = b->pair_desc.as<PairDesc>();
+        b->pp.n_pairs = (uint32_t)nl;
+        b->pp.queue = b->queue.as<uint32_t>();
+        b->pp.rowbuf = b->rowbuf.as<int32_t>();
+        b->pp.row_stride = stride;
+        b->pp.match = match;
+        b->pp.mismatch = mismatch;
+        b->pp.gap = gap;
+        b->kernel_name = local ? "pair_fill_kernel<RL=4,SW,no-traceback>" : "pair_fill_kernel<RL=4,NW,no-traceback>";
+    }
+    guard.b = nullptr;
+    *out = b;
+    return PWA_OK;
+}
+
+int pwa_batch_run(pwa_batch* b, void* stream_v) {
+    if (!b) return PWA_E_INVALID;
+    pwa_ctx* ctx = b->ctx;
+    hipStream_t st = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
+    HIPC(ctx, hipEventRecord(b->ev0, st));
+    if (b->n_live) {
+        HIPC(ctx, hipMemsetAsync(b->queue.p, 0, 16, st));
+        if (b->use_strips) {
+            hipLaunchKernelGGL(b->kern->fn, dim3(b->grid), dim3(64), 0, st, b->bp);
+        } else {
+            hipLaunchKernelGGL(pair_fill_fn(b->mode == PWA_MODE_SW, false, false), dim3(b->pair_grid), dim3(64), 0, st, b->pp);
+        }
+        HIPC(ctx, hipGetLastError());
+    }
+    HIPC(ctx, hipEventRecord(b->ev1, st));
+    b->ran = true;
+    return PWA_OK;
+}
+
+int32_t* pwa_batch_d_scores(pwa_batch* b) { return b ? b->scores.as<int32_t>() : nullptr; }
+
+int pwa_batch_last_ms(pwa_batch* b, float* ms) {
+    if (!b || !ms || !b->ran) return PWA_E_INVALID;
+    HIPC(b->ctx, hipEventSynchronize(b->ev1));
+    HIPC(b->ctx, hipEventElapsedTime(ms, b->ev0, b->ev1));
+    return PWA_OK;
+}
+
+int pwa_batch_info(const pwa_batch* b, uint64_t* cells, uint64_t* padded_cells, uint64_t* n_tasks,
+                   const char** kernel_name) {
+    if (!b) return PWA_E_INVALID;
+    if (cells) *cells = b->cells;
+    if (padded_cells) *padded_cells = b->padded_cells;
+    if (n_tasks) *n_tasks = b->use_strips ? b->bp.n_tasks : b->n_live;
+    if (kernel_name) *kernel_name = b->kernel_name.c_str();
+    return PWA_OK;
+}
+
+int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint32_t* end_j_out) {
+    if (!b || !score_out) return PWA_E_INVALID;
+    pwa_ctx* ctx = b->ctx;
+    if ((end_i_out || end_j_out) && !b->want_end) return fail(ctx, PWA_E_INVALID, "batch was created without end cells");
+    if (!b->ran) return fail(ctx, PWA_E_INVALID, "pwa_batch_run has not been called");
+    HIPC(ctx, hipEventSynchronize(b->ev1));
+    if (b->use_strips || b->n_live == 0) {
+        HIPC(ctx, hipMemcpy(score_out, b->scores.p, b->n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (b->want_end) {   // only reachable with no live pairs
+            if (end_i_out) std::memcpy(end_i_out, b->host_end_i.data(), b->n_pairs * 4);
+            if (end_j_out) std::memcpy(end_j_out, b->host_end_j.data(), b->n_pairs * 4);
+        }
+        return PWA_OK;
+    }
+    std::vector<PairResult> res(b->n_live);
+    HIPC(ctx, hipMemcpy(res.data(), b->pair_res.p, b->n_live * sizeof(PairResult), hipMemcpyDeviceToHost));
+    std::memcpy(score_out, b->host_scores.data(), b->n_pairs * sizeof(int32_t));
+    if (b->want_end) {
+        if (end_i_out) std::memcpy(end_i_out, b->host_end_i.data(), b->n_pairs * 4);
+        if (end_j_out) std::memcpy(end_j_out, b->host_end_j.data(), b->n_pairs * 4);
+    }
+    for (uint64_t q = 0; q < b->n_live; ++q) {
+        const uint32_t k = b->live_idx[q];
+        score_out[k] = res[q].score;
+        if (end_i_out) end_i_out[k] = res[q].end_i;
+        if (end_j_out) end_j_out[k] = res[q].end_j;
+    }
+    // keep the device-side score vector coherent with what was fetched
+    HIPC(ctx, hipMemcpy(b->scores.p, score_out, b->n_pairs * sizeof(int32_t), hipMemcpyHostToDevice));
+    return PWA_OK;
+}
+
+void pwa_batch_destroy(pwa_batch* b) {
+    if (!b) return;
+    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    delete b;
+}
+
+int pwa_scores(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* seq_bytes,
+               const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
+               uint64_t n_pairs, int32_t* score_out, uint32_t* end_i_out, uint32_t* end_j_out) {
+    if (!ctx || !score_out) return PWA_E_INVALID;
+    pwa_batch* b = nullptr;
+    int rc = pwa_batch_create(ctx, mode, match, mismatch, gap, seq_bytes, seq_off, n_seq, pair_a, pair_b, n_pairs,
+                              (end_i_out || end_j_out) ? 1 : 0, &b);
+    if (rc != PWA_OK) return rc;
+    rc = pwa_batch_run(b, nullptr);
+    if (rc == PWA_OK) rc = pwa_batch_fetch(b, score_out, end_i_out, end_j_out);
+    pwa_batch_destroy(b);
+    return rc;
+}
+
+// ------------------------------------------------------------------------- full alignments
+int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* seq_bytes,
+                    const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
+                    uint64_t n_pairs, int32_t* score_out, uint8_t* ops, const uint64_t* ops_off, uint64_t* n_ops,
+                    uint64_t* end_cells, uint64_t* start_cells) {
+    if (!ctx) return PWA_E_INVALID;
+    if (mode != PWA_MODE_NW && mode != PWA_MODE_SW) return fail(ctx, PWA_E_INVALID, "unknown mode");
+    if (!seq_off || !score_out || !ops_off || !n_ops || (n_pairs && (!pair_a || !pair_b)))
+        return fail(ctx, PWA_E_INVALID, "null input");
+    if (n_pairs >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "more than 2^32-2 pairs in one batch");
+    for (uint64_t k = 0; k < n_pairs; ++k)
+        if (pair_a[k] >= n_seq || pair_b[k] >= n_seq) return fail(ctx, PWA_E_INVALID, "pair index out of range");
+    HIPC(ctx, hipSetDevice(ctx->device));
+    const bool local = mode == PWA_MODE_SW;
+    auto slen = [&](uint32_t s) -> uint64_t { return seq_off[s + 1] - seq_off[s]; };
+    ctx->fill_ms = ctx->tb_ms = 0.f;
+    ctx->band_bytes = 0;
+
+    // raw-byte arena of the used sequences
+    std::vector<uint8_t> is_used(n_seq, 0);
+    for (uint64_t k = 0; k < n_pairs; ++k) is_used[pair_a[k]] = is_used[pair_b[k]] = 1;
+    std::vector<uint64_t> aoff(n_seq, 0);
+    uint64_t arena_bytes = 0;
+    for (uint32_t s = 0; s < n_seq; ++s)
+        if (is_used[s]) {
+            aoff[s] = arena_bytes;
+            arena_bytes += align_up(slen(s) + 1, 16);
+        }
+    arena_bytes += 256;
+    DevBuf arena;
+    {
+        std::vector<uint8_t> host_arena(arena_bytes, 0);
+        for (uint32_t s = 0; s < n_seq; ++s)
+            if (is_used[s] && slen(s)) std::memcpy(host_arena.data() + aoff[s], seq_bytes + seq_off[s], slen(s));
+        HIPC(ctx, arena.alloc(arena_bytes));
+        HIPC(ctx, hipMemcpy(arena.p, host_arena.data(), arena_bytes, hipMemcpyHostToDevice));
+    }
+
+    // pairs are processed in chunks whose traceback bands fit the free HBM
+    size_t free_b = 0, total_b = 0;
+    HIPC(ctx, hipMemGetInfo(&free_b, &total_b));
+    const uint64_t budget = std::max<uint64_t>((uint64_t)(free_b * 0.8), 64ull << 20);
+
+    uint64_t k0 = 0;
+    while (k0 < n_pairs) {
+        uint64_t k1 = k0, band = 0, opsb = 0, max_m = 0;
+        while (k1 < n_pairs) {
+            const uint64_t n = slen(pair_a[k1]), m = slen(pair_b[k1]);
+            if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
+            const uint64_t need = (n && m) ? align_up(tb_band_bytes(n, m), 256) : 0;
+            if (k1 > k0 && band + need + opsb + n + m > budget) break;
+            band += need;
+            opsb += align_up(n + m + 1, 16);
+            max_m = std::max(max_m, m);
+            ++k1;
+        }
+        const uint64_t nc = k1 - k0;
+        if (band + opsb > budget && nc == 1 && band + opsb > (uint64_t)(free_b * 0.97))
+            return fail(ctx, PWA_E_NOMEM, "traceback band of a single pair exceeds free HBM");
+        DevBuf d_band, d_ops, d_res, d_desc, d_rows, d_queue;
+        HIPC(ctx, d_band.alloc(band));
+        HIPC(ctx, d_ops.alloc(opsb));
+        HIPC(ctx, d_res.alloc(nc * sizeof(PairResult)));
+        HIPC(ctx, d_queue.alloc(64));
+        std::vector<PairResult> res(nc);
+        std::vector<PairDesc> pd;
+        std::vector<uint32_t> live;   // index into chunk
+        std::vector<uint64_t> ooff(nc);
+        uint64_t bo = 0, oo = 0;
+        for (uint64_t q = 0; q < nc; ++q) {
+            const uint64_t k = k0 + q, n = slen(pair_a[k]), m = slen(pair_b[k]);
+            std::memset(&res[q], 0, sizeof(PairResult));
+            ooff[q] = oo;
+            if (n && m) {
+                PairDesc d;
+                std::memset(&d, 0, sizeof d);
+                d.pat = arena.as<uint8_t>() + aoff[pair_a[k]];
+                d.txt = arena.as<uint8_t>() + aoff[pair_b[k]];
+                d.n = (int32_t)n;
+                d.m = (int32_t)m;
+                d.tb = d_band.as<uint8_t>() + bo;
+                d.res = d_res.as<PairResult>() + q;
+                d.ops = d_ops.as<uint8_t>() + oo;
+                d.ops_cap = (uint32_t)std::min<uint64_t>(n + m, 0xffffffffu);
+                pd.push_back(d);
+                live.push_back((uint32_t)q);
+                bo += align_up(tb_band_bytes(n, m), 256);
+                ctx->band_bytes += tb_band_bytes(n, m);
+            } else if (!local) {
+                res[q].score = wrap_mul((int64_t)(n + m), gap);
+                res[q].end_i = (uint32_t)n;
+                res[q].end_j = (uint32_t)m;
+            }
+            oo += align_up(n + m + 1, 16);
+        }
+        HIPC(ctx, hipMemcpy(d_res.p, res.data(), nc * sizeof(PairResult), hipMemcpyHostToDevice));
+        if (!pd.empty()) {
+            HIPC(ctx, d_desc.alloc(pd.size() * sizeof(PairDesc)));
+            HIPC(ctx, hipMemcpy(d_desc.p, pd.data(), pd.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
+            PairParams G;
+            std::memset(&G, 0, sizeof G);
+            G.pairs = d_desc.as<PairDesc>();
+            G.n_pairs = (uint32_t)pd.size();
+            G.queue = d_queue.as<uint32_t>();
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(pd.size(), (uint64_t)ctx->num_cu * 16);
+            G.row_stride = align_up(max_m + 64, 64);
+            HIPC(ctx, d_rows.alloc((size_t)grid * 2 * G.row_stride * sizeof(int32_t)));
+            G.rowbuf = d_rows.as<int32_t>();
+            G.match = match;
+            G.mismatch = mismatch;
+            G.gap = gap;
+            HIPC(ctx, hipMemsetAsync(d_queue.p, 0, 16, ctx->stream));
+            HIPC(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+            hipLaunchKernelGGL(pair_fill_fn(local, true, false), dim3(grid), dim3(64), 0, ctx->stream, G);
+            HIPC(ctx, hipGetLastError());
+            HIPC(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+            hipLaunchKernelGGL(pair_tb_fn(local), dim3((G.n_pairs + 63) / 64), dim3(64), 0, ctx->stream, G);
+            HIPC(ctx, hipGetLastError());
+            HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+            HIPC(ctx, hipStreamSynchronize(ctx->stream));
+            float a = 0, c = 0;
+            HIPC(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+            HIPC(ctx, hipEventElapsedTime(&c, ctx->ev[1], ctx->ev[2]));
+            ctx->fill_ms += a;
+            ctx->tb_ms += c;
+        }
+        HIPC(ctx, hipMemcpy(res.data(), d_res.p, nc * sizeof(PairResult), hipMemcpyDeviceToHost));
+        std::vector<uint8_t> host_ops(opsb);
+        HIPC(ctx, hipMemcpy(host_ops.data(), d_ops.p, opsb, hipMemcpyDeviceToHost));
+        for (uint64_t q = 0; q < nc; ++q) {
+            const uint64_t k = k0 + q, n = slen(pair_a[k]), m = slen(pair_b[k]);
+            uint64_t cnt = res[q].n_ops;
+            if (!(n && m)) {
+                // one side empty: NW walks the boundary (hw2.cpp:170-179), SW emits nothing (239)
+                cnt = local ? 0 : n + m;
+                for (uint64_t o = 0; o < cnt; ++o) ops[ops_off[k] + o] = n ? 'D' : 'I';
+                if (start_cells) start_cells[2 * k] = start_cells[2 * k + 1] = 0;
+            } else {
+                if (res[q].overflow) return fail(ctx, PWA_E_CAPACITY, "internal: traceback longer than n+m");
+                std::memcpy(ops + ops_off[k], host_ops.data() + ooff[q], cnt);
+                if (start_cells) {
+                    start_cells[2 * k] = res[q].start_i;
+                    start_cells[2 * k + 1] = res[q].start_j;
+                }
+            }
+            score_out[k] = res[q].score;
+            n_ops[k] = cnt;
+            if (end_cells) {
+                end_cells[2 * k] = res[q].end_i;
+                end_cells[2 * k + 1] = res[q].end_j;
+            }
+        }
+        k0 = k1;
+    }
+    return PWA_OK;
+}
+
+int pwa_align(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* pattern, uint64_t n,
+              const uint8_t* text, uint64_t m, int32_t* score, uint8_t* ops, uint64_t ops_cap, uint64_t* n_ops,
+              uint64_t end_cell[2], uint64_t start_cell[2]) {
+    if (!ctx) return PWA_E_INVALID;
+    if (!score || !ops || !n_ops || (n && !pattern) || (m && !text)) return fail(ctx, PWA_E_INVALID, "null input");
+    if (ops_cap < n + m) return fail(ctx, PWA_E_CAPACITY, "ops_cap must be at least n + m");
+    std::vector<uint8_t> bytes(n + m);
+    if (n) std::memcpy(bytes.data(), pattern, n);
+    if (m) std::memcpy(bytes.data() + n, text, m);
+    const uint64_t off[3] = {0, n, n + m};
+    const uint32_t a = 0, b = 1;
+    const uint64_t ooff = 0;
+    return pwa_align_batch(ctx, mode, match, mismatch, gap, bytes.data(), off, 2, &a, &b, 1, score, ops, &ooff, n_ops,
+                           end_cell, start_cell);
+}
+
+int pwa_align_last_stats(const pwa_ctx* ctx, float* fill_ms, float* traceback_ms, uint64_t* band_bytes) {
+    if (!ctx) return PWA_E_INVALID;
+    if (fill_ms) *fill_ms = ctx->fill_ms;
+    if (traceback_ms) *traceback_ms = ctx->tb_ms;
+    if (band_bytes) *band_bytes = ctx->band_bytes;
+    return PWA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+/*
+ * pwalign.h -- C ABI of the MI355X-native pairwise-alignment engine (libpwalign.so).
+ *
+ * Drop-in boundary for the DP hot path of the reference program
+ *   /root/reference/Local_Global_Alignment/hw2.cpp
+ * The reference has no FFI; its only callable surface for this path is the two C++ functions
+ *   AlignmentResult* globalAlignmentNeedlemanWunsch(const string&, const string&, int, int, int)  hw2.cpp:118
+ *   AlignmentResult* localAlignmentSmithWaterman  (const string&, const string&, int, int, int)  hw2.cpp:192
+ * called once per pair from the loop at hw2.cpp:328-338.  Each entry point below names the
+ * reference lines it replaces.  INTEGRATION.md shows the stub a maintainer of hw2.cpp would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer is caller-owned HOST memory unless the
+ *     parameter name starts with d_ (then it is a DEVICE pointer on the context's GPU);
+ *   - sequences are RAW BYTES compared for equality (hw2.cpp:142, 208): any alphabet, case-sensitive;
+ *   - scores are int32 with the reference's recurrences and tie-breaks; results are bit-identical
+ *     to hw2.cpp wherever hw2.cpp itself does not overflow int;
+ *   - every function returns PWA_OK (0) or a negative PWA_E_* code; nothing throws, exits or
+ *     prints across the ABI; pwa_last_error() gives the text of the last failure on a context;
+ *   - a context is bound to ONE GPU and is not thread-safe: one context per host thread.
+ *   - there is NO CPU fallback: without a usable GPU pwa_ctx_create fails with PWA_E_NODEVICE.
+ */
+#ifndef PWALIGN_H
+#define PWALIGN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PWA_MODE_NW 0 /* global, hw2.cpp:118-190 (tie-break diag >= left >= up, 145-153)      */
+#define PWA_MODE_SW 1 /* local,  hw2.cpp:192-265 (tie-break zero > diag > up > left, 214-222) */
+
+#define PWA_OK 0
+#define PWA_E_INVALID (-1)     /* bad argument (null pointer, unknown mode, index out of range) */
+#define PWA_E_NODEVICE (-2)    /* no usable gfx950 device / HIP runtime                         */
+#define PWA_E_HIP (-3)         /* a HIP call failed (text in pwa_last_error)                     */
+#define PWA_E_NOMEM (-4)       /* host or device allocation failed                              */
+#define PWA_E_CAPACITY (-5)    /* caller buffer too small / problem exceeds an index width       */
+
+typedef struct pwa_ctx pwa_ctx;
+typedef struct pwa_batch pwa_batch;
+
+/* Library / build identification: "pwalign <ver> gfx950". */
+const char *pwa_version(void);
+const char *pwa_strerror(int code);
+
+/* Context = one GPU (HIP device ordinal) + its streams and workspaces. */
+int pwa_ctx_create(int device, pwa_ctx **out);
+void pwa_ctx_destroy(pwa_ctx *ctx);
+const char *pwa_last_error(const pwa_ctx *ctx);
+
+/*
+ * Scores of many pairs (the scores-only pass over hw2.cpp's pair loop 328-338; for -l the
+ * reference selects the best pair from `result->score` alone, 352-356).
+ *
+ *   seq_bytes/seq_off : n_seq sequences, sequence s = seq_bytes[seq_off[s] .. seq_off[s+1])
+ *   pair_a/pair_b     : pair k aligns pattern = sequence pair_a[k] (rows, hw2 "patterns")
+ *                       against reference/text = sequence pair_b[k] (columns, hw2 "references")
+ *   score_out[k]      : NW: dp[n][m] (hw2.cpp:186);  SW: max cell (hw2.cpp:225-229)
+ *   end_i_out/end_j_out (each may be NULL): the cell the reference's traceback starts from --
+ *                       NW (n, m); SW the FIRST maximum in row-major order, (0,0) if all zero.
+ */
+int pwa_scores(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const uint8_t *seq_bytes,
+               const uint64_t *seq_off, uint32_t n_seq, const uint32_t *pair_a, const uint32_t *pair_b,
+               uint64_t n_pairs, int32_t *score_out, uint32_t *end_i_out, uint32_t *end_j_out);
+
+/*
+ * The same pass split into prepare / run / fetch so that a caller can keep inputs resident in
+ * HBM, time the kernels alone, and hand the device-side score vector to a collective
+ * (RCCL all-gather over xGMI) without a host round trip.
+ *   pwa_batch_create  uploads the sequences, builds the wave-task list (host), allocates outputs;
+ *   pwa_batch_run     enqueues the kernels on `stream` (a hipStream_t, NULL = the context's own
+ *                     stream) -- asynchronous, no host synchronisation, graph-capturable;
+ *   pwa_batch_d_scores  device pointer to int32[n_pairs] in pair order (valid until destroy);
+ *   pwa_batch_fetch   synchronises the stream and copies scores (and end cells, if requested at
+ *                     create time) to host buffers.
+ */
+int pwa_batch_create(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const uint8_t *seq_bytes,
+                     const uint64_t *seq_off, uint32_t n_seq, const uint32_t *pair_a, const uint32_t *pair_b,
+                     uint64_t n_pairs, int want_end_cells, pwa_batch **out);
+int pwa_batch_run(pwa_batch *b, void *stream);
+int32_t *pwa_batch_d_scores(pwa_batch *b);
+int pwa_batch_fetch(pwa_batch *b, int32_t *score_out, uint32_t *end_i_out, uint32_t *end_j_out);
+/* Facts about the prepared batch for reporting: cells = sum n*m; padded_cells = cells the kernels
+ * actually evaluate (register-tile padding); kernel_name = the dominant kernel instantiation. */
+int pwa_batch_info(const pwa_batch *b, uint64_t *cells, uint64_t *padded_cells, uint64_t *n_tasks,
+                   const char **kernel_name);
+/* Device time of the most recent pwa_batch_run in ms (HIP events on the run's stream); the call
+ * synchronises the run. */
+int pwa_batch_last_ms(pwa_batch *b, float *ms);
+void pwa_batch_destroy(pwa_batch *b);
+
+/*
+ * Full alignment of ONE pair: matrix fill with the traceback band in HBM + traceback walk on
+ * the device.  Replaces one call of hw2.cpp:118 / hw2.cpp:192 up to (not including) the string
+ * post-processing prepareCigarString / prepareMDZString (59-116), which stays on the host.
+ *
+ *   ops      : receives the walk's op bytes 'M' (diagonal), 'D' (up: pattern char vs '-'),
+ *              'I' (left: '-' vs text char) in TRACEBACK order, i.e. exactly the contents of
+ *              the reference's `tracebacks` vector (hw2.cpp:161, 237) before any reversal;
+ *   ops_cap  : capacity of ops; n + m always suffices (PWA_E_CAPACITY otherwise);
+ *   end_cell : {i, j} the walk starts from (NW: n, m; SW: first row-major maximum);
+ *   start_cell: {i, j} where it stops (NW: 0,0).   Either may be NULL.
+ */
+int pwa_align(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const uint8_t *pattern, uint64_t n,
+              const uint8_t *text, uint64_t m, int32_t *score, uint8_t *ops, uint64_t ops_cap, uint64_t *n_ops,
+              uint64_t end_cell[2], uint64_t start_cell[2]);
+
+/* Device time in ms of the fill kernel(s) / traceback kernel of the last pwa_align on ctx, and
+ * the bytes of traceback band it wrote to HBM (for roofline accounting). */
+int pwa_align_last_stats(const pwa_ctx *ctx, float *fill_ms, float *traceback_ms, uint64_t *band_bytes);
+
+/*
+ * Full alignment of many pairs (the -g path needs every pair's alignment: hw2.cpp:344).
+ * ops of pair k are written at ops[ops_off[k] .. ops_off[k] + n_ops[k]); the caller sizes
+ * ops_off so that pair k has room for n_k + m_k bytes.
+ */
+int pwa_align_batch(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const uint8_t *seq_bytes,
+                    const uint64_t *seq_off, uint32_t n_seq, const uint32_t *pair_a, const uint32_t *pair_b,
+                    uint64_t n_pairs, int32_t *score_out, uint8_t *ops, const uint64_t *ops_off, uint64_t *n_ops,
+                    uint64_t *end_cells /* 2*n_pairs or NULL */, uint64_t *start_cells /* 2*n_pairs or NULL */);
+
+/*
+ * Host-side post-processing of one alignment (no GPU work): everything hw2.cpp derives from
+ * the walk -- the gapped strings (hw2.cpp:164-184 / 240-259), prepareCigarString (59-78),
+ * prepareMDZString (80-116) and overlapLongestExactMatch (267-278) -- so that the five fields
+ * of the reference's AlignmentResult (hw2.cpp:17-23) can be rebuilt from pwa_align's output.
+ *   ops / n_ops / end_cell : as returned by pwa_align (ops in traceback order)
+ *   aligned_pattern, aligned_reference : n_ops + 1 bytes each (NUL-terminated)
+ *   cigar : pwa_cigar_bound(n_ops) bytes;  mdz : pwa_mdz_bound(n_ops) bytes
+ * Note the reference's conventions are kept verbatim: 'D' = pattern char against '-',
+ * 'I' = '-' against text char, MD:Z mismatches print the REFERENCE character and deletions
+ * print the PATTERN characters.
+ */
+uint64_t pwa_cigar_bound(uint64_t n_ops);
+uint64_t pwa_mdz_bound(uint64_t n_ops);
+int pwa_format_alignment(const uint8_t *pattern, uint64_t n, const uint8_t *text, uint64_t m, const uint8_t *ops,
+                         uint64_t n_ops, const uint64_t end_cell[2], char *aligned_pattern, char *aligned_reference,
+                         char *cigar, char *mdz, int32_t *overlap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PWALIGN_H */

@@ -28,3 +28,30 @@ def B(s):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def load_pkg():
+    """Import the package whose directory name has a hyphen (bioinformatics-algorithms_amd)."""
+    import importlib.util
+    name = "bioinformatics_algorithms_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    d = os.path.join(ROOT, "bioinformatics-algorithms_amd")
+    spec = importlib.util.spec_from_file_location(name, os.path.join(d, "__init__.py"), submodule_search_locations=[d])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return load_pkg()
+
+
+@pytest.fixture(scope="session")
+def ctx(pkg):
+    """A context on GPU 0.  No skip on failure: on the GPU box the HIP path must be the one that runs."""
+    c = pkg.Context(0)
+    yield c
+    c.close()

@@ -1,0 +1,108 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol the
+header declares, refuses to work without a GPU (no CPU fallback), and its host-only
+post-processing (CIGAR / MD:Z / gapped strings / overlap) matches the reference fixtures."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+import oracle_lib as O
+from conftest import B, ROOT, load_golden, load_pkg
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "pwalign.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(pwa_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    pkg = load_pkg()
+    L = pkg.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 19
+    for s in syms:
+        assert hasattr(L, s), s
+    assert sorted(pkg.EXPORTS) == syms
+    assert L.pwa_version().decode().endswith("gfx950")
+
+
+def test_library_has_gfx950_code_object():
+    pkg = load_pkg()
+    out = subprocess.run(["strings", "-a", pkg.LIB_PATH], stdout=subprocess.PIPE).stdout
+    assert b"gfx950" in out and b"batch_scores_kernel" in out and b"pair_fill_kernel" in out
+
+
+def _no_gpu():
+    return not os.path.exists("/dev/kfd")
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="only meaningful on a machine without a GPU")
+def test_no_cpu_fallback_without_gpu():
+    pkg = load_pkg()
+    with pytest.raises(pkg.PwaError):
+        pkg.Context(0)
+
+
+def test_error_strings():
+    L = load_pkg().lib()
+    assert L.pwa_strerror(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5, -99):
+        assert L.pwa_strerror(code)
+    assert L.pwa_ctx_create(0, None) == -1
+
+
+@pytest.mark.parametrize("name", ["bundled", "edge", "random"])
+def test_format_alignment_matches_reference(name):
+    """ops + end cell (from the oracle's walk) -> strings through the C ABI == reference strings."""
+    pkg = load_pkg()
+    for rec in load_golden(name):
+        p, t = B(rec["p"]), B(rec["t"])
+        o = O.align(rec["mode"], p, t, *rec["scoring"])
+        f = pkg.format_alignment(p, t, o["ops"], o["end"])
+        assert f["cigar"] == B(rec["cigar"])
+        assert f["mdz"] == B(rec["mdz"])
+        assert f["aligned_pattern"] == B(rec["aligned_pattern"])
+        assert f["aligned_reference"] == B(rec["aligned_reference"])
+        assert f["overlap"] == rec["overlap"]
+
+
+def test_format_alignment_rejects_inconsistent_input():
+    pkg = load_pkg()
+    with pytest.raises(pkg.PwaError):
+        pkg.format_alignment(b"AC", b"AC", b"MMM", (2, 2))
+    with pytest.raises(pkg.PwaError):
+        pkg.format_alignment(b"AC", b"AC", b"MX", (2, 2))
+
+
+def test_cli_argument_errors_match_reference(tmp_path):
+    """Paths of the CLI that never reach the GPU: usage, unreadable input, count mismatch,
+    neither -g nor -l (empty output), unwritable output with zero pairs."""
+    pkg = load_pkg()
+    exe = pkg.CLI_PATH
+    assert os.path.exists(exe), "host CLI not built"
+    import shutil
+    from conftest import GOLDEN
+    cli = load_golden("cli")
+    for f in ("patterns.fasta", "texts.fasta"):
+        shutil.copyfile(os.path.join(GOLDEN, f), tmp_path / f)
+    for name, content in cli["files"].items():
+        (tmp_path / name).write_bytes(B(content))
+    ran = 0
+    for case in cli["cases"]:
+        needs_gpu = case["rc"] == 0 and case["output"] not in (None, "")
+        if needs_gpu or "nodir/out.txt" in case["args"]:
+            continue
+        outp = tmp_path / "out.txt"
+        if outp.exists():
+            outp.unlink()
+        pr = subprocess.run([exe] + case["args"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert pr.returncode == case["rc"], case["args"]
+        assert pr.stderr.replace(exe.encode(), b"hw2") == B(case["stderr"]), case["args"]
+        got = outp.read_bytes() if outp.exists() else None
+        want = B(case["output"]) if case["output"] is not None else None
+        assert got == want, case["args"]
+        ran += 1
+    assert ran >= 5

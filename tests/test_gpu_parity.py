@@ -1,0 +1,265 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the committed reference fixtures.
+Every test here needs a real MI355X: run with `pytest -m gpu`."""
+import hashlib
+import os
+import random
+import shutil
+import subprocess
+
+import pytest
+
+import oracle_lib as O
+from conftest import B, GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+SCORINGS = [(1, -1, -1), (2, -3, -5), (5, -4, -4), (1, -3, -1), (0, 0, 0), (1, 1, 1), (-1, 2, 1), (3, -1, 2),
+            (1, -1, 0), (2, -1, -3)]
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def check_alignment(got, want):
+    """got: Context.align dict; want: oracle dict or fixture record."""
+    for k in ("score", "cigar", "mdz", "aligned_pattern", "aligned_reference", "overlap"):
+        w = want[k]
+        if isinstance(w, str):
+            w = B(w)
+        assert got[k] == w, (k, got[k], w)
+
+
+# ------------------------------------------------------------------ full alignments (fill + traceback)
+@pytest.mark.parametrize("name", ["bundled", "edge", "random"])
+def test_align_matches_reference_fixtures(ctx, name):
+    recs = load_golden(name)
+    for rec in recs:
+        got = ctx.align(rec["mode"], B(rec["p"]), B(rec["t"]), *rec["scoring"])
+        check_alignment(got, rec)
+
+
+def test_align_ops_and_cells_match_oracle(ctx):
+    rng = random.Random(11)
+    for it in range(120):
+        alpha = rng.choice([b"ACGT", b"AC", bytes(range(65, 91))])
+        p = bytes(rng.choice(alpha) for _ in range(rng.randint(1, 700)))
+        t = bytes(rng.choice(alpha) for _ in range(rng.randint(1, 700)))
+        sc = rng.choice(SCORINGS)
+        for mode in ("nw", "sw"):
+            got = ctx.align(mode, p, t, *sc, raw=True)
+            want = O.align(mode, p, t, *sc)
+            assert got["score"] == want["score"]
+            assert got["ops"] == want["ops"]
+            assert tuple(got["end"]) == tuple(want["end"])
+            assert tuple(got["start"]) == tuple(want["start"])
+
+
+def test_align_kats_long_pairs(ctx):
+    """SURVEY.md 8(d) generator KATs incl. C2 (10k x 10k): strings compared by sha256 of the
+    reference's output."""
+    for rec in load_golden("kat"):
+        p, t = O.gen(*rec["gen_p"]), O.gen(*rec["gen_t"])
+        got = ctx.align(rec["mode"], p, t, *rec["scoring"])
+        assert got["score"] == rec["score"]
+        assert got["overlap"] == rec["overlap"]
+        assert len(got["aligned_pattern"]) == rec["aligned_len"]
+        assert sha(got["cigar"]) == rec["cigar_sha256"]
+        assert sha(got["mdz"]) == rec["mdz_sha256"]
+        assert sha(got["aligned_pattern"]) == rec["aligned_pattern_sha256"]
+        assert sha(got["aligned_reference"]) == rec["aligned_reference_sha256"]
+
+
+def test_align_batch_matches_oracle(ctx):
+    rng = random.Random(5)
+    seqs = [bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, 400))) for _ in range(40)]
+    pa = [rng.randrange(40) for _ in range(100)]
+    pb = [rng.randrange(40) for _ in range(100)]
+    for mode in ("nw", "sw"):
+        for sc in [(1, -1, -1), (2, -3, -5)]:
+            res = ctx.align_batch(mode, seqs, pa, pb, *sc)
+            for k, r in enumerate(res):
+                want = O.align(mode, seqs[pa[k]], seqs[pb[k]], *sc)
+                assert r["score"] == want["score"], (mode, k)
+                assert r["ops"] == want["ops"], (mode, k)
+                assert tuple(r["end"]) == tuple(want["end"])
+                assert tuple(r["start"]) == tuple(want["start"])
+
+
+# ------------------------------------------------------------------ scores-only batches
+def test_scores_c3_small_fixture(ctx):
+    c3 = load_golden("c3_small")
+    pats = [O.gen(1, 0, i, c3["pattern_len"]) for i in range(c3["n_patterns"])]
+    txts = [O.gen(1, 1, i, c3["text_len"]) for i in range(c3["n_texts"])]
+    seqs = pats + txts
+    pa, pb = [], []
+    for i in range(len(pats)):
+        for j in range(len(txts)):
+            pa.append(i)
+            pb.append(len(pats) + j)
+    for key, tab in c3["scorings"].items():
+        sc = tuple(int(x) for x in key.split(","))
+        got = ctx.scores("sw", seqs, pa, pb, *sc)
+        assert got == [r[0] for r in tab]
+        s, ei, ej = ctx.scores("sw", seqs, pa, pb, *sc, want_end=True)
+        assert [list(x) for x in zip(s, ei, ej)] == tab
+
+
+def test_scores_c4_small_fixture(ctx):
+    c4 = load_golden("c4_small")
+    seqs = [O.gen(1, 2, i, c4["len"]) for i in range(c4["n_seq"])]
+    pa, pb = [], []
+    for i in range(16):
+        for j in range(i + 1, 16):
+            pa.append(i)
+            pb.append(j)
+    got = ctx.scores("nw", seqs, pa, pb, *c4["scoring"])
+    assert got == c4["scores_upper_triangle"] and sum(got) == 11397
+    # the plain-H kernel (gap-shift not applicable with these magnitudes) must agree as well
+    got2 = ctx.scores("nw", seqs, pa, pb, 100, -90, -70)
+    want2 = [O.score("nw", seqs[a], seqs[b], 100, -90, -70)[0] for a, b in zip(pa, pb)]
+    assert got2 == want2
+
+
+@pytest.mark.parametrize("alphabet", [b"ACGT", b"ACGTN", bytes(range(65, 91)), bytes(range(1, 256))])
+def test_scores_random_batches_match_oracle(ctx, alphabet):
+    rng = random.Random(len(alphabet))
+    lens = [0, 1, 2, 3, 4, 5, 63, 64, 65, 127, 128, 129, 151, 152, 153, 200, 300, 520]
+    seqs = []
+    for _ in range(70):
+        n = rng.choice(lens) if rng.random() < 0.5 else rng.randint(1, 330)
+        seqs.append(bytes(rng.choice(alphabet) for _ in range(n)))
+    seqs.append(seqs[3])
+    pa = [rng.randrange(len(seqs)) for _ in range(700)]
+    pb = [rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]) if rng.random() < 0.8 else rng.randrange(len(seqs))
+          for _ in range(700)]
+    for sc in SCORINGS:
+        for mode in ("nw", "sw"):
+            got = ctx.scores(mode, seqs, pa, pb, *sc)
+            want = [O.score(mode, seqs[a], seqs[b], *sc)[0] for a, b in zip(pa, pb)]
+            bad = [k for k in range(len(pa)) if got[k] != want[k]]
+            assert not bad, (mode, sc, bad[:5], [(len(seqs[pa[k]]), len(seqs[pb[k]]), got[k], want[k]) for k in bad[:5]])
+
+
+def test_scores_end_cells_match_oracle(ctx):
+    rng = random.Random(77)
+    seqs = [bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, 600))) for _ in range(30)]
+    pa = [rng.randrange(30) for _ in range(150)]
+    pb = [rng.randrange(30) for _ in range(150)]
+    for sc in [(1, -1, -1), (1, 1, 1), (0, 0, 0), (2, -3, -5)]:
+        for mode in ("nw", "sw"):
+            s, ei, ej = ctx.scores(mode, seqs, pa, pb, *sc, want_end=True)
+            for k in range(len(pa)):
+                w = O.score(mode, seqs[pa[k]], seqs[pb[k]], *sc)
+                assert (s[k], ei[k], ej[k]) == tuple(w), (mode, sc, k)
+
+
+def test_scores_many_strips_and_long_texts(ctx):
+    """patterns spanning several register strips, texts with every length residue mod 4."""
+    pats = [O.gen(3, 0, i, n) for i, n in enumerate([1000, 999, 700, 513, 512, 511, 129, 1])]
+    txts = [O.gen(3, 1, i, m) for i, m in enumerate([2000, 2001, 2002, 2003, 5])]
+    seqs = pats + txts
+    pa = [i for i in range(len(pats)) for _ in txts]
+    pb = [len(pats) + j for _ in pats for j in range(len(txts))]
+    for sc in [(1, -1, -1), (5, -4, -4), (100, -90, -70)]:
+        for mode in ("nw", "sw"):
+            got = ctx.scores(mode, seqs, pa, pb, *sc)
+            want = [O.score(mode, seqs[a], seqs[b], *sc)[0] for a, b in zip(pa, pb)]
+            assert got == want, (mode, sc)
+
+
+def test_batch_object_reuse(ctx, pkg):
+    seqs = [O.gen(9, 0, i, 150) for i in range(130)] + [O.gen(9, 1, 0, 777)]
+    pa = list(range(130))
+    pb = [130] * 130
+    b = ctx.batch("sw", seqs, pa, pb, 1, -1, -1)
+    info = b.info()
+    assert info["cells"] == 130 * 150 * 777 and info["padded_cells"] >= info["cells"]
+    b.run()
+    first = b.fetch()
+    b.run()
+    assert b.fetch() == first
+    assert b.last_ms() > 0
+    assert first == [O.score("sw", s, seqs[130], 1, -1, -1)[0] for s in seqs[:130]]
+    b.close()
+
+
+# ------------------------------------------------------------------ size-independent properties at larger sizes
+def _path_score(p, t, ops, end, match, mismatch, gap):
+    i, j = end
+    tot = 0
+    for o in ops:
+        if o == ord("M"):
+            i -= 1
+            j -= 1
+            tot += match if p[i] == t[j] else mismatch
+        elif o == ord("D"):
+            i -= 1
+            tot += gap
+        else:
+            j -= 1
+            tot += gap
+    return tot, (i, j)
+
+
+def test_large_pair_properties(ctx):
+    """20k x 20k: the returned path must re-score to the returned score, which must equal the
+    oracle's score-only DP; NW == transposed NW; SW path starts where the walk says."""
+    p, t = O.gen(1, 0, 7, 20000), O.gen(1, 1, 7, 20000)
+    for mode in ("nw", "sw"):
+        got = ctx.align(mode, p, t, 1, -1, -1, raw=True)
+        want = O.score(mode, p, t, 1, -1, -1)
+        assert got["score"] == want[0]
+        assert tuple(got["end"]) == (want[1], want[2])
+        tot, start = _path_score(p, t, got["ops"], got["end"], 1, -1, -1)
+        assert tot == got["score"]
+        assert start == tuple(got["start"])
+    assert ctx.align("nw", t, p, 1, -1, -1, raw=True)["score"] == ctx.align("nw", p, t, 1, -1, -1, raw=True)["score"]
+
+
+# ------------------------------------------------------------------ the hw2-compatible CLI
+def test_cli_reproduces_reference_goldens(pkg, tmp_path):
+    for flag, golden in (("-g", "global.txt"), ("-l", "local.txt")):
+        out = tmp_path / golden
+        rc, err = O.run_cli(pkg.CLI_PATH, [flag, "-p", os.path.join(GOLDEN, "patterns.fasta"), "-t",
+                                           os.path.join(GOLDEN, "texts.fasta"), "-o", out, "-s", 1, -1, -1])
+        assert rc == 0 and err == b"", err
+        assert out.read_bytes() == open(os.path.join(GOLDEN, golden), "rb").read()
+
+
+def test_cli_cases_match_reference(pkg, tmp_path):
+    cli = load_golden("cli")
+    for f in ("patterns.fasta", "texts.fasta"):
+        shutil.copyfile(os.path.join(GOLDEN, f), tmp_path / f)
+    for name, content in cli["files"].items():
+        (tmp_path / name).write_bytes(B(content))
+    exe = pkg.CLI_PATH
+    for case in cli["cases"]:
+        outp = tmp_path / "out.txt"
+        if outp.exists():
+            outp.unlink()
+        pr = subprocess.run([exe] + case["args"], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert pr.returncode == case["rc"], (case["args"], pr.stderr)
+        assert pr.stderr.replace(exe.encode(), b"hw2") == B(case["stderr"]), case["args"]
+        got = outp.read_bytes() if outp.exists() else None
+        want = B(case["output"]) if case["output"] is not None else None
+        assert got == want, case["args"]
+
+
+def test_cli_many_pairs_against_oracle_cli(pkg, tmp_path):
+    rng = random.Random(3)
+    with open(tmp_path / "p.fa", "w") as fp, open(tmp_path / "t.fa", "w") as ft:
+        for i in range(60):
+            p = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 200)))
+            t = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 400)))
+            fp.write(">p%d\n%s\n" % (i, p))
+            ft.write(">t%d\n%s\n" % (i, t))
+    O.oracle()
+    for flag in ("-g", "-l"):
+        for sc in [(1, -1, -1), (2, -3, -5)]:
+            a, b = tmp_path / "a.txt", tmp_path / "b.txt"
+            args = [flag, "-p", "p.fa", "-t", "t.fa", "-s", *sc]
+            rc1, _ = O.run_cli(pkg.CLI_PATH, args + ["-o", a], cwd=tmp_path)
+            rc2, _ = O.run_cli(O.ORACLE_CLI, args + ["-o", b], cwd=tmp_path)
+            assert rc1 == rc2 == 0
+            assert a.read_bytes() == b.read_bytes()
