@@ -125,7 +125,14 @@ __global__ __launch_bounds__(64) void batch_scores_kernel(const BatchParams P) {
 
     for (;;) {
         uint32_t tid = 0;
-        if (lane == 0) tid = atomicAdd(P.queue, 1u);
+        {
+            // The electing lane id is made opaque on every trip: with a plain `lane == 0` hipcc threads
+            // this branch together with a later `if (lane == 0)` of the previous trip, lane 0 then loops
+            // apart from lanes 1..63 and the readfirstlane below no longer sees lane 0 (observed: hang).
+            int elect = lane;
+            asm volatile("" : "+v"(elect));
+            if (elect == 0) tid = atomicAdd(P.queue, 1u);
+        }
         tid = __builtin_amdgcn_readfirstlane(tid);
         if (tid >= P.n_tasks) break;
 

@@ -81,7 +81,14 @@ __global__ __launch_bounds__(64) void pair_fill_kernel(const PairParams G) {
   int32_t* const rowbuf = G.rowbuf + (size_t)blockIdx.x * 2 * G.row_stride;
   for (;;) {
     uint32_t pid = 0;
-    if (lane == 0) pid = atomicAdd(G.queue, 1u);
+    {
+        // The electing lane id is made opaque on every trip: with a plain `lane == 0` hipcc threads
+        // this branch together with a later `if (lane == 0)` of the previous trip, lane 0 then loops
+        // apart from lanes 1..63 and the readfirstlane below no longer sees lane 0 (observed: hang).
+        int elect = lane;
+        asm volatile("" : "+v"(elect));
+        if (elect == 0) pid = atomicAdd(G.queue, 1u);
+    }
     pid = __builtin_amdgcn_readfirstlane(pid);
     if (pid >= G.n_pairs) break;
     const PairDesc P = G.pairs[pid];

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -680,13 +681,21 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
             G.gap = gap;
             HIPC(ctx, hipMemsetAsync(d_queue.p, 0, 16, ctx->stream));
             HIPC(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+            const bool dbg = std::getenv("PWA_DEBUG") != nullptr;
+            if (dbg) std::fprintf(stderr, "[pwa] fill launch grid=%u pairs=%u stride=%llu band=%llu\n", grid, G.n_pairs,
+                                  (unsigned long long)G.row_stride, (unsigned long long)band);
             hipLaunchKernelGGL(pair_fill_fn(local, true, false), dim3(grid), dim3(64), 0, ctx->stream, G);
             HIPC(ctx, hipGetLastError());
             HIPC(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+            if (dbg) {
+                HIPC(ctx, hipStreamSynchronize(ctx->stream));
+                std::fprintf(stderr, "[pwa] fill done\n");
+            }
             hipLaunchKernelGGL(pair_tb_fn(local), dim3((G.n_pairs + 63) / 64), dim3(64), 0, ctx->stream, G);
             HIPC(ctx, hipGetLastError());
             HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
             HIPC(ctx, hipStreamSynchronize(ctx->stream));
+            if (dbg) std::fprintf(stderr, "[pwa] traceback done\n");
             float a = 0, c = 0;
             HIPC(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
             HIPC(ctx, hipEventElapsedTime(&c, ctx->ev[1], ctx->ev[2]));
