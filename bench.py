@@ -1,0 +1,376 @@
+#!/usr/bin/env python3
+"""bench.py -- GCUPS of the hw2.cpp DP hot path on MI355X (contract: one JSON line on rank 0).
+
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c4|c2|c5]
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM.
+Default workload (BASELINE.json configs[2], the config the >=1 TCUPS target is quoted on):
+  c3  batched Smith-Waterman, linear gap, int32, scores only: 4096 patterns (150 bp) x 256 texts
+      (10 kbp) = 1 048 576 pairs = 1.573e12 DP cells per step and per GPU, scoring 1/-1/-1.
+      N > 1: every rank gets its own 256 texts (weak scaling), one RCCL all-gather of the per-pair
+      int32 scores per step.
+Other workloads (reported the same way, not the headline line):
+  c4  all-pairs NW of 1024 sequences x 1000 bp (523 776 pairs), pairs sharded over the ranks
+      (strong scaling) + all-gather;   c2 / c5  one SW 10k x 10k / NW 100k x 100k pair with the
+      traceback band written to HBM (does not shard: replicas only).
+
+Inputs come from the counter-based generator of SURVEY.md 8(d) (splitmix64), restated here in numpy.
+The oracle / compiled reference are used ONLY for the cpu_baseline leg and to verify a sample of the
+GPU results after the timed region.
+"""
+import argparse
+import ctypes as C
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.join(ROOT, "bioinformatics-algorithms_amd")
+
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s (= 157.3 TFLOP/s fp32 / 2)
+# VALU instructions per DP cell in the unrolled column block of each instantiation (counted in the
+# gfx950 ISA, see DESIGN.md "ops per cell"; tools/valu_per_cell.py re-derives them from the .so)
+VALU_PER_CELL = {"BM_SW,SC_PERM": 4.9, "BM_SW,SC_CMP": 6.9, "BM_NW,SC_PERM": 4.5, "BM_NW,SC_CMP": 6.5,
+                 "BM_NWG,SC_PERM": 2.5, "BM_NWG,SC_CMP": 4.5}
+
+
+def load_pkg():
+    name = "bioinformatics_algorithms_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(PKG_DIR, "__init__.py"),
+                                                  submodule_search_locations=[PKG_DIR])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# ----------------------------------------------------------------------------- synthetic input
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15))
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def gen(seed, stream, ident, length):
+    """base(seed,stream,id,pos) = "ACGT"[splitmix64(key + pos) >> 62]."""
+    with np.errstate(over="ignore"):
+        key = _splitmix64(_splitmix64(np.uint64(seed)) ^ (np.uint64(stream) << np.uint64(56)) ^ np.uint64(ident))
+        v = _splitmix64(key + np.arange(length, dtype=np.uint64))
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[(v >> np.uint64(62)).astype(np.int64)].tobytes()
+
+
+assert gen(1, 0, 0, 32) == b"GCAAAATTTCCTCTACCCAATTGGACGCATGC"   # SURVEY.md 8(d) self-check
+
+
+class DevPtr:
+    """Expose a raw device pointer to torch (for the RCCL all-gather) without copying."""
+
+    def __init__(self, ptr, n, typestr="<i4"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+# ----------------------------------------------------------------------------- CPU baseline leg
+def cpu_baseline(mode, pairs, seqs, scoring, budget_s=12.0, max_pairs=1024):
+    """Time the unmodified reference (oracle/_ref, kind "reference") or the C restatement (kind
+    "port") on a bounded sample of the same workload, 1 thread; then all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    kind = "reference" if O.have_ref() else "port"
+    fn = (lambda p, t: O.ref_align(mode, p, t, *scoring)["score"]) if kind == "reference" else \
+         (lambda p, t: O.align(mode, p, t, *scoring)["score"])
+    t0 = time.perf_counter()
+    cells, scores = 0, []
+    for (a, b) in pairs[:max_pairs]:
+        scores.append(fn(seqs[a], seqs[b]))
+        cells += len(seqs[a]) * len(seqs[b])
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    out = {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": kind,
+           "sample": "first %d pairs of the workload (%.3g cells, %.1f s), full int+char matrices as hw2.cpp, g++ -O2"
+                     % (len(scores), cells, dt)}
+    # all host cores: one process per core over disjoint shards (the reference itself is single-threaded)
+    try:
+        ncore = min(len(os.sched_getaffinity(0)), 16)   # the 1-GPU box's CPU share
+        import multiprocessing as mp
+        per = max(1, min(len(scores), max_pairs) // 2)
+        shards = [[pairs[(w * per + k) % len(pairs)] for k in range(per)] for w in range(ncore)]
+        with mp.get_context("fork").Pool(ncore) as pool:
+            t1 = time.perf_counter()
+            res = pool.starmap(_cpu_shard, [(mode, sh, seqs, scoring, kind) for sh in shards])
+            dt_all = time.perf_counter() - t1
+        out["all_cores"] = {"value": sum(res) / dt_all / 1e9, "cores": ncore}
+    except Exception as e:   # noqa: BLE001 -- the extra figure is optional
+        out["all_cores"] = {"error": str(e)}
+    try:
+        with open("/proc/cpuinfo") as f:
+            out["cpu_model"] = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+    except Exception:   # noqa: BLE001
+        pass
+    return out, scores
+
+
+def _cpu_shard(mode, shard, seqs, scoring, kind):
+    import oracle_lib as O
+    cells = 0
+    for (a, b) in shard:
+        if kind == "reference":
+            O.ref_align(mode, seqs[a], seqs[b], *scoring)
+        else:
+            O.align(mode, seqs[a], seqs[b], *scoring)
+        cells += len(seqs[a]) * len(seqs[b])
+    return cells
+
+
+# ----------------------------------------------------------------------------- workloads
+def build_c3(rank, n_patterns=4096, n_texts=256, plen=150, tlen=10000):
+    pats = [gen(1, 0, p, plen) for p in range(n_patterns)]
+    txts = [gen(1, 1, rank * n_texts + t, tlen) for t in range(n_texts)]
+    seqs = pats + txts
+    pa = np.repeat(np.arange(n_patterns, dtype=np.uint32), n_texts)
+    pb = np.tile(np.arange(n_texts, dtype=np.uint32) + np.uint32(n_patterns), n_patterns)
+    desc = {"workload": "c3: batched SW scores-only, %d patterns x %d bp  X  %d texts x %d bp per GPU, 1/-1/-1"
+                        % (n_patterns, plen, n_texts, tlen),
+            "pairs_per_gpu": int(n_patterns * n_texts), "scoring": [1, -1, -1]}
+    return "sw", seqs, pa, pb, (1, -1, -1), desc
+
+
+def build_c4(rank, world, n_seq=1024, slen=1000):
+    seqs = [gen(1, 2, i, slen) for i in range(n_seq)]
+    ii, jj = np.triu_indices(n_seq, k=1)
+    n_pairs = len(ii)
+    per = (n_pairs + world - 1) // world
+    lo, hi = rank * per, min(n_pairs, (rank + 1) * per)
+    pa = ii[lo:hi].astype(np.uint32)
+    pb = jj[lo:hi].astype(np.uint32)
+    desc = {"workload": "c4: all-pairs NW scores, %d seq x %d bp (%d pairs) sharded over %d GPU(s), 1/-1/-1"
+                        % (n_seq, slen, n_pairs, world),
+            "pairs_total": int(n_pairs), "scoring": [1, -1, -1]}
+    return "nw", seqs, pa, pb, (1, -1, -1), desc
+
+
+# ----------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c2", "c5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--small", action="store_true", help="reduced sizes (functional check only; line is marked invalid)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch   # noqa: F811
+        import torch.distributed as dist   # noqa: F811
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+
+    pkg = load_pkg()
+    ctx = pkg.Context(local_rank)
+
+    if args.workload in ("c2", "c5"):
+        return bench_single_pair(args, pkg, ctx, rank, world, dist, torch)
+
+    if args.workload == "c3":
+        kw = dict(n_patterns=256, n_texts=16, tlen=2000) if args.small else {}
+        mode, seqs, pa, pb, scoring, desc = build_c3(rank, **kw)
+        scaling = "weak"
+    else:
+        kw = dict(n_seq=128) if args.small else {}
+        mode, seqs, pa, pb, scoring, desc = build_c4(rank, world, **kw)
+        scaling = "strong"
+
+    batch = ctx.batch(mode, seqs, pa, pb, *scoring)
+    info = batch.info()
+    n_pairs = len(pa)
+
+    stream = None
+    gathered = None
+    mine = None
+    if world > 1:
+        stream = torch.cuda.current_stream().cuda_stream
+        mine = torch.as_tensor(DevPtr(batch.d_scores(), n_pairs), device="cuda")
+        per = n_pairs
+        if args.workload == "c4":   # equal-count blocks, last one padded
+            per = (desc["pairs_total"] + world - 1) // world
+            if n_pairs < per:
+                pad = torch.zeros(per, dtype=torch.int32, device="cuda")
+                mine_src = mine
+                mine = pad
+                mine[:n_pairs].copy_(mine_src)   # refreshed every step below
+                desc["_padded"] = True
+        gathered = torch.empty(world * per, dtype=torch.int32, device="cuda")
+
+    def step():
+        batch.run(stream)
+        if world > 1:
+            if desc.get("_padded"):
+                mine[:n_pairs].copy_(torch.as_tensor(DevPtr(batch.d_scores(), n_pairs), device="cuda"))
+            dist.all_gather_into_tensor(gathered, mine)   # RCCL over xGMI: per-pair int32 scores
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        else:
+            batch.last_ms()   # event-synchronises the library's stream
+
+    for _ in range(args.warmup):
+        step()
+    if args.warmup == 0:
+        batch.run(stream)   # make sync() well defined
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = batch.run_times(min(args.steps, 64))   # HIP events on the launch stream, per step
+    cells = info["cells"]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([float(cells)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        cells_total = float(c.item())
+    else:
+        cells_total = float(cells)
+
+    scores = batch.fetch(numpy_out=True)
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    gcups = cells_total * args.steps / elapsed / 1e9
+    k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    kern = info["kernel"]
+    key = ",".join(kern[kern.index("<") + 1:-1].split(",")[1:]) if "<" in kern else ""
+    ops = VALU_PER_CELL.get(key)
+    padded = info["padded_cells"] or cells
+    alg_bytes = sum(len(s) for s in seqs) + 4 * n_pairs            # inputs once + 4 B per pair
+    kernel_gcups = cells / (k_ms * 1e-3) / 1e9
+    roofline = {
+        "bound": "valu",   # int32 VALU issue: scores-only SW moves ~5e-6 B/cell over HBM
+        "kernel": kern,
+        "achieved": (padded / (k_ms * 1e-3)) * ops / 1e12 if ops else None,
+        "peak": VALU_PEAK_TOPS,
+        "unit": "Tiop/s",
+        "frac": ((padded / (k_ms * 1e-3)) * ops / 1e12) / VALU_PEAK_TOPS if ops else None,
+        "valu_ops_per_cell": ops,
+        "kernel_ms": k_ms,
+        "kernel_gcups": kernel_gcups,
+        "padded_cells_per_launch": padded,
+        "traffic": None,
+        "hbm": {"algorithmic_bytes_per_launch": alg_bytes, "achieved_GBs": alg_bytes / (k_ms * 1e-3) / 1e9,
+                "peak_GBs": HBM_PEAK_GBS, "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "notional_4B_per_cell_frac": kernel_gcups * 4 / HBM_PEAK_GBS,
+                "note": "scores-only pass is not HBM-bound; the notional figure prices the int32 score band "
+                        "as if it were written (north-star accounting), it is NOT traffic"},
+    }
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        roofline["traffic"] = tj.get("hbm_bytes_per_launch")
+        roofline["traffic_source"] = tj.get("source")
+
+    line = {
+        "metric": "GCUPS (billion DP cells/s) SW linear-gap, 1/2/4/8xMI355X; bit-exact vs hw2.cpp"
+                  if args.workload == "c3" else "GCUPS (billion DP cells/s) NW linear-gap all-pairs; bit-exact vs hw2.cpp",
+        "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "int32", "data": "synthetic",
+        "config": {k: v for k, v in desc.items() if not k.startswith("_")},
+        "roofline": roofline,
+    }
+    if args.small:
+        line["invalid"] = "reduced sizes (--small): functional check only"
+
+    if world == 1 and not args.no_cpu_baseline:
+        pairs = list(zip(pa[:4096].tolist(), pb[:4096].tolist()))
+        base, ref_scores = cpu_baseline(mode, pairs, seqs, scoring)
+        line["cpu_baseline"] = base
+        ok = all(int(scores[k]) == ref_scores[k] for k in range(len(ref_scores)))
+        line["verified_vs_cpu"] = {"pairs": len(ref_scores), "bit_exact": bool(ok)}
+        if not ok:
+            line["invalid"] = "GPU scores differ from the CPU baseline"
+    line["checksum"] = int(np.asarray(scores, dtype=np.int64).sum())
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_single_pair(args, pkg, ctx, rank, world, dist, torch):
+    """c2 / c5: one big pair, full fill + traceback band in HBM.  Does not shard: replicas only."""
+    if args.workload == "c2":
+        n = m = 2000 if args.small else 10000
+        mode, label = "sw", "c2: SW 1 pair %dx%d, traceback band in HBM" % (n, m)
+    else:
+        n = m = 5000 if args.small else 100000
+        mode, label = "nw", "c5: NW 1 pair %dx%d, traceback band in HBM" % (n, m)
+    p, t = gen(1, 0, 0, n), gen(1, 1, 0, m)
+    for _ in range(args.warmup):
+        ctx.align(mode, p, t, 1, -1, -1, raw=True)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    fill, tb = [], []
+    for _ in range(args.steps):
+        r = ctx.align(mode, p, t, 1, -1, -1, raw=True)
+        st = ctx.align_stats()
+        fill.append(st["fill_ms"])
+        tb.append(st["traceback_ms"])
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        dist.destroy_process_group()
+        return
+    st = ctx.align_stats()
+    cells = float(n) * m
+    k_ms = float(np.mean(fill))
+    band = st["band_bytes"]
+    line = {
+        "metric": "GCUPS (billion DP cells/s) single pair with traceback; bit-exact vs hw2.cpp",
+        "value": cells * world * args.steps / elapsed / 1e9, "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": label + " (replicas only: a single pair does not shard)", "scoring": [1, -1, -1],
+                   "includes": "H2D of the pair, fill, traceback walk, D2H of the ops"},
+        "roofline": {"bound": "hbm", "kernel": "pair_fill_kernel<RL=4,%s,TB>" % mode.upper(),
+                     "achieved": band / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": band / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": band, "kernel_ms": k_ms, "traceback_ms": float(np.mean(tb)),
+                     "kernel_gcups": cells / (k_ms * 1e-3) / 1e9},
+        "result": {"score": r["score"], "n_ops": len(r["ops"])},
+    }
+    if args.small:
+        line["invalid"] = "reduced sizes (--small): functional check only"
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

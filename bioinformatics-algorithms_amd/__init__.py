@@ -25,7 +25,7 @@ MODE = {"nw": 0, "sw": 1, "global": 0, "local": 1}
 EXPORTS = [
     "pwa_version", "pwa_strerror", "pwa_ctx_create", "pwa_ctx_destroy", "pwa_last_error", "pwa_scores",
     "pwa_batch_create", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_fetch", "pwa_batch_info",
-    "pwa_batch_last_ms", "pwa_batch_destroy", "pwa_align", "pwa_align_last_stats", "pwa_align_batch",
+    "pwa_batch_last_ms", "pwa_batch_run_times", "pwa_batch_destroy", "pwa_align", "pwa_align_last_stats", "pwa_align_batch",
     "pwa_cigar_bound", "pwa_mdz_bound", "pwa_format_alignment",
 ]
 
@@ -64,6 +64,7 @@ def lib():
     L.pwa_batch_fetch.argtypes = [vp, i32p, u32p, u32p]
     L.pwa_batch_info.argtypes = [vp, u64p, u64p, u64p, C.POINTER(C.c_char_p)]
     L.pwa_batch_last_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.pwa_batch_run_times.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     L.pwa_batch_destroy.argtypes = [vp]
     L.pwa_batch_destroy.restype = None
     L.pwa_align.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_uint64, vp, C.c_uint64, i32p, vp,
@@ -241,6 +242,12 @@ class Batch:
         ms = C.c_float(0)
         self._ctx._check(self._L.pwa_batch_last_ms(self._h, C.byref(ms)), "pwa_batch_last_ms")
         return ms.value
+
+    def run_times(self, cap=64):
+        arr = (C.c_float * cap)()
+        n = C.c_int(0)
+        self._ctx._check(self._L.pwa_batch_run_times(self._h, arr, cap, C.byref(n)), "pwa_batch_run_times")
+        return list(arr[:n.value])
 
     def info(self):
         cells, padded, nt = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)

@@ -141,7 +141,9 @@ struct pwa_batch {
     std::vector<int32_t> host_scores;   // trivial pairs resolved on the host
     std::vector<uint32_t> host_end_i, host_end_j;
     std::string kernel_name;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    static constexpr int kRing = 64;          // event pairs of the most recent runs
+    hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
+    uint64_t n_runs = 0;
     bool ran = false;
 };
 
@@ -259,8 +261,10 @@ int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, c
     HIPC(ctx, b->scores.alloc(std::max<uint64_t>(n_pairs, 1) * sizeof(int32_t)));
     HIPC(ctx, hipMemcpy(b->scores.p, b->host_scores.data(), n_pairs * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPC(ctx, b->queue.alloc(64));
-    HIPC(ctx, hipEventCreate(&b->ev0));
-    HIPC(ctx, hipEventCreate(&b->ev1));
+    for (int e = 0; e < pwa_batch::kRing; ++e) {
+        HIPC(ctx, hipEventCreate(&b->ev0[e]));
+        HIPC(ctx, hipEventCreate(&b->ev1[e]));
+    }
     if (live.empty()) {
         b->kernel_name = "none";
         guard.b = nullptr;
@@ -480,7 +484,8 @@ int pwa_batch_run(pwa_batch* b, void* stream_v) {
     if (!b) return PWA_E_INVALID;
     pwa_ctx* ctx = b->ctx;
     hipStream_t st = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
-    HIPC(ctx, hipEventRecord(b->ev0, st));
+    const int slot = (int)(b->n_runs % pwa_batch::kRing);
+    HIPC(ctx, hipEventRecord(b->ev0[slot], st));
     if (b->n_live) {
         HIPC(ctx, hipMemsetAsync(b->queue.p, 0, 16, st));
         if (b->use_strips) {
@@ -490,7 +495,8 @@ int pwa_batch_run(pwa_batch* b, void* stream_v) {
         }
         HIPC(ctx, hipGetLastError());
     }
-    HIPC(ctx, hipEventRecord(b->ev1, st));
+    HIPC(ctx, hipEventRecord(b->ev1[slot], st));
+    ++b->n_runs;
     b->ran = true;
     return PWA_OK;
 }
@@ -499,8 +505,22 @@ int32_t* pwa_batch_d_scores(pwa_batch* b) { return b ? b->scores.as<int32_t>() :
 
 int pwa_batch_last_ms(pwa_batch* b, float* ms) {
     if (!b || !ms || !b->ran) return PWA_E_INVALID;
-    HIPC(b->ctx, hipEventSynchronize(b->ev1));
-    HIPC(b->ctx, hipEventElapsedTime(ms, b->ev0, b->ev1));
+    const int slot = (int)((b->n_runs - 1) % pwa_batch::kRing);
+    HIPC(b->ctx, hipEventSynchronize(b->ev1[slot]));
+    HIPC(b->ctx, hipEventElapsedTime(ms, b->ev0[slot], b->ev1[slot]));
+    return PWA_OK;
+}
+
+int pwa_batch_run_times(pwa_batch* b, float* ms_out, int cap, int* n_out) {
+    if (!b || !ms_out || !n_out || cap < 0) return PWA_E_INVALID;
+    const uint64_t have = std::min<uint64_t>(b->n_runs, pwa_batch::kRing);
+    const int n = (int)std::min<uint64_t>(have, (uint64_t)cap);
+    for (int k = 0; k < n; ++k) {   // oldest of the last n first
+        const int slot = (int)((b->n_runs - n + k) % pwa_batch::kRing);
+        HIPC(b->ctx, hipEventSynchronize(b->ev1[slot]));
+        HIPC(b->ctx, hipEventElapsedTime(&ms_out[k], b->ev0[slot], b->ev1[slot]));
+    }
+    *n_out = n;
     return PWA_OK;
 }
 
@@ -519,7 +539,7 @@ int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint3
     pwa_ctx* ctx = b->ctx;
     if ((end_i_out || end_j_out) && !b->want_end) return fail(ctx, PWA_E_INVALID, "batch was created without end cells");
     if (!b->ran) return fail(ctx, PWA_E_INVALID, "pwa_batch_run has not been called");
-    HIPC(ctx, hipEventSynchronize(b->ev1));
+    HIPC(ctx, hipEventSynchronize(b->ev1[(b->n_runs - 1) % pwa_batch::kRing]));
     if (b->use_strips || b->n_live == 0) {
         HIPC(ctx, hipMemcpy(score_out, b->scores.p, b->n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost));
         if (b->want_end) {   // only reachable with no live pairs
@@ -549,8 +569,10 @@ int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint3
 void pwa_batch_destroy(pwa_batch* b) {
     if (!b) return;
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
-    if (b->ev0) (void)hipEventDestroy(b->ev0);
-    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    for (int e = 0; e < pwa_batch::kRing; ++e) {
+        if (b->ev0[e]) (void)hipEventDestroy(b->ev0[e]);
+        if (b->ev1[e]) (void)hipEventDestroy(b->ev1[e]);
+    }
     delete b;
 }
 

@@ -91,6 +91,9 @@ int pwa_batch_info(const pwa_batch *b, uint64_t *cells, uint64_t *padded_cells, 
 /* Device time of the most recent pwa_batch_run in ms (HIP events on the run's stream); the call
  * synchronises the run. */
 int pwa_batch_last_ms(pwa_batch *b, float *ms);
+/* Device times (ms, oldest first) of up to `cap` most recent runs (at most 64 are kept): each is
+ * bracketed by HIP events recorded on the stream the kernels were enqueued on. */
+int pwa_batch_run_times(pwa_batch *b, float *ms_out, int cap, int *n_out);
 void pwa_batch_destroy(pwa_batch *b);
 
 /*
