@@ -117,8 +117,14 @@ __device__ __forceinline__ void dp_block(int (&H)[R], const uint32_t (&pk)[R / 4
     for (int k = 0; k < C; ++k) bot[k] = u[k];
 }
 
+// Register budget: H[R] + R/4 packed symbols + ~30 live temporaries.  The second launch-bound is the
+// number of waves per SIMD the allocation must leave room for (512 registers per SIMD lane, AGPRs
+// included): without it hipcc parks 12 values in AGPRs at R = 152, the wave allocates 268 registers
+// and only ONE wave fits per SIMD -- which halves VALU throughput (one wave issues every 4 cycles).
+constexpr int strip_waves_per_simd(int R) { return R > 104 ? 2 : (R > 80 ? 3 : 4); }
+
 template <int R, int MODE, int SCORE>
-__global__ __launch_bounds__(64) void batch_scores_kernel(const BatchParams P) {
+__global__ __launch_bounds__(64, strip_waves_per_simd(R)) void batch_scores_kernel(const BatchParams P) {
     constexpr int Q = R / 4;
     const int lane = threadIdx.x;
     int32_t* const hand = P.hand + (size_t)blockIdx.x * P.hand_stride;

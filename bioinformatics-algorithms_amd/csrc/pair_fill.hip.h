@@ -1,24 +1,30 @@
-// pair_fill.hip.h -- full DP fill of ONE pair with the traceback band written to HBM, plus the
+// pair_fill.hip.h -- full DP fill of a pair with the traceback band written to HBM, plus the
 // traceback walk (gfx950 / MI355X).
 //
 // Replaces hw2.cpp:119-156 + 158-181 (NW) and hw2.cpp:193-231 + 233-257 (SW): the reference fills
 // an int matrix and a char matrix row by row (5 B/cell) and walks the char matrix backwards.
 //
 // Mapping:
-//   * the matrix is cut into horizontal STRIPES of 64*RL rows; one 64-lane wavefront owns a stripe,
-//     lane k owns RL consecutive rows of it;
+//   * the matrix is cut into horizontal STRIPES of 64*RL rows; one 64-lane wavefront (= one
+//     single-wave workgroup) owns a stripe, lane k owns RL consecutive rows of it;
 //   * the wave sweeps its stripe along an anti-diagonal front: at step t lane k computes column
 //     c = t - k of its RL rows.  "left" and most "diag"/"up" operands are the lane's own registers;
 //     the row above a lane's first row comes from lane k-1 one step earlier through a DPP
 //     wave-shift (no LDS), as does the text character, which enters at lane 0 and travels down;
-//   * lane 0 is fed from the stripe above through a row buffer in HBM ([column] int32), read and
-//     written 64 columns at a time as one coalesced 256-B wave access;
+//   * the stripes of one pair run CONCURRENTLY on different CUs as a software pipeline: stripe s
+//     consumes the bottom row of stripe s-1 two 64-step chunks behind it.  The hand-off goes
+//     through a per-stripe row buffer in HBM: write-through (sc1) stores, the storing wave's
+//     vmcnt(0) drain, one sc1 progress-counter store by one lane; the consumer polls that counter
+//     with sc1 loads and reads the row with sc1 loads (cdna_hip_programming.md Guideline 16, R1 /
+//     MI355X_MICROARCH.md "valid forms", row 1).  Stripe tasks are dealt in global order from an
+//     atomic queue, so the producer of any task is always already running: no residency
+//     assumption, no deadlock for any grid size; every spin is bounded;
 //   * traceback codes (1 B/cell, the reference's char matrix) leave in SKEWED layout
 //     tb[stripe][step][lane][RL]: every step each wave stores 64*RL contiguous bytes (256 B for
 //     RL = 4); the optional int32 score band uses the same layout (1 KiB per step);
-//   * SW keeps, per (lane, row-slot), the first strict maximum in column order; the final
-//     reduction picks max score, then smallest i (then j is already the smallest) = the
-//     reference's first row-major maximum (hw2.cpp:225-229).
+//   * SW keeps, per (lane, row-slot), the first strict maximum in column order; a stripe reduces
+//     to (score, smallest i, its j); the walk kernel takes the first best stripe = the reference's
+//     first row-major maximum (hw2.cpp:225-229).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,34 +42,64 @@ struct PairResult {
     uint32_t pad;
 };
 
+struct StripeBest {       // per stripe task (SW)
+    int32_t score;
+    uint32_t i, j;
+    uint32_t pad;
+};
+
 struct PairDesc {          // one pair of a launch
     const uint8_t* pat;   // n bytes (+ slack)
     const uint8_t* txt;   // m bytes (+ slack)
     int32_t n, m;
     uint8_t* tb;          // skewed traceback band (unused when the kernel is built without TB)
     int32_t* sband;       // optional skewed int32 score band (same indexing)
+    int32_t* rows;        // bottom rows of stripes 0 .. n_stripes-2, row_stride int32 each
     PairResult* res;
     uint8_t* ops;         // traceback output, capacity ops_cap
     uint32_t ops_cap;
-    uint32_t pad;
+    uint32_t first_task;  // index of this pair's stripe 0 in the task list
+    uint32_t n_stripes;
+    uint32_t row_stride;  // >= m + 64
+};
+
+struct StripeTask {
+    uint32_t pair, stripe;
 };
 
 struct PairParams {
     const PairDesc* pairs;
-    uint32_t n_pairs;
-    uint32_t* queue;        // atomic pair counter (zeroed before every launch)
-    int32_t* rowbuf;        // per workgroup: 2 x row_stride int32 (bottom row of previous / current stripe)
-    uint64_t row_stride;    // >= max m + 64
+    const StripeTask* tasks;
+    uint32_t n_pairs, n_tasks;
+    uint32_t* queue;        // [0] atomic task counter, [1] error flag (both zeroed before every launch)
+    uint32_t* progress;     // per task: number of finished 64-step chunks (zeroed before every launch)
+    StripeBest* best;       // per task (SW)
     int32_t match, mismatch, gap;
 };
 
 __device__ __forceinline__ int p_addw(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 __device__ __forceinline__ int p_mulw(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
 
-// value of lane (k-1) for lane k, `fill` for lane 0
+// lane k <- lane k-1; lane 0 keeps `fill`
 __device__ __forceinline__ int wave_shr1(int fill, int v) {
     return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
+// lane k <- lane k+1; lane 63 keeps `fill`
+__device__ __forceinline__ int wave_shl1(int fill, int v) {
+    return __builtin_amdgcn_update_dpp(fill, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+
+#define PWA_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// Pointers that arrive inside descriptors are generic to the compiler; as FLAT accesses they would
+// also tick lgkmcnt and force an lgkmcnt(0) wait into every step.  All of them are hipMalloc memory.
+#define PWA_GLOBAL __attribute__((address_space(1)))
+typedef PWA_GLOBAL uint8_t g_u8;
+typedef PWA_GLOBAL const uint8_t g_cu8;
+typedef PWA_GLOBAL uint32_t g_u32;
+typedef PWA_GLOBAL int32_t g_i32;
+typedef PWA_GLOBAL const int32_t g_ci32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int RL>
 __device__ __forceinline__ size_t tb_index(int i, int j, int m) {   // i, j >= 1
@@ -75,186 +111,296 @@ __device__ __forceinline__ size_t tb_index(int i, int j, int m) {   // i, j >= 1
     return ((s * T + (size_t)(j - 1 + k)) * 64 + k) * RL + r;
 }
 
+// One anti-diagonal step of a stripe.  EDGE = some lanes of this step may lie outside the matrix
+// or compute the matrix's last column.
+template <int RL, bool LOCAL, bool TB, bool SBAND, bool EDGE>
+__device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i_first, const int (&pc)[RL], int (&hl)[RL],
+                                            int& diag0, int& bottom, int& tch, int& topv, int& tcv, int& coll,
+                                            int (&bs)[RL], int (&bj)[RL], int match, int mismatch, int gap,
+                                            g_u8* tbs, g_i32* sbs, PWA_GLOBAL PairResult* res) {
+    const int up_in = wave_shr1(topv, bottom);   // dp[i_first-1][j]; lane 0: the staged row above the stripe
+    tch = wave_shr1(tcv, tch);                   // text char of column c; lane 0: the staged text
+    topv = wave_shl1(topv, topv);                // rotate the staged vectors: lane 0 sees the next column next step
+    tcv = wave_shl1(tcv, tcv);
+    const int c = t - lane;
+    uint32_t codes = 0;
+    int hnew[RL];
+    const bool active = !EDGE || (c >= 0 && c < m);
+    if (active) {
+        const int j = c + 1;
+        int dg = diag0, up = up_in;
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {
+            const int sc = (pc[r] == tch) ? match : mismatch;
+            const int tdiag = p_addw(dg, sc);
+            const int lf = hl[r];
+            const int ug = p_addw(up, gap), lg = p_addw(lf, gap);
+            int h, code;
+            if (LOCAL) {
+                h = max(0, max(tdiag, max(ug, lg)));                                                   // hw2.cpp:211
+                code = (h == 0) ? TB_STOP : (h == tdiag) ? TB_DIAG : (h == ug) ? TB_UP : TB_LEFT;      // 214-222
+                if (h > bs[r]) {                                                                       // 225-229
+                    bs[r] = h;
+                    bj[r] = j;
+                }
+            } else {
+                h = tdiag;                                                                             // 142-153
+                code = TB_DIAG;
+                if (lg > h) { h = lg; code = TB_LEFT; }
+                if (ug > h) { h = ug; code = TB_UP; }
+                if (EDGE && (i_first + r) == n && j == m) res->score = h;                              // 186
+            }
+            codes |= (uint32_t)code << (8 * r);
+            dg = lf;
+            up = h;
+            hl[r] = h;
+            hnew[r] = h;
+        }
+        diag0 = up_in;
+        bottom = up;
+    } else {
+#pragma unroll
+        for (int r = 0; r < RL; ++r) hnew[r] = 0;
+    }
+    coll = wave_shl1(bottom, coll);   // lane 63 inserts its bottom-row value (column t-63), the rest shifts down
+    if (TB) {
+        if (RL == 4) {
+            ((g_u32*)tbs)[(size_t)t * 64 + lane] = codes;
+        } else {
+#pragma unroll
+            for (int r = 0; r < RL; ++r) tbs[((size_t)t * 64 + lane) * RL + r] = (uint8_t)(codes >> (8 * r));
+        }
+    }
+    if (SBAND) {
+#pragma unroll
+        for (int r = 0; r < RL; ++r) sbs[((size_t)t * 64 + lane) * RL + r] = hnew[r];
+    }
+}
+
 template <int RL, bool LOCAL, bool TB, bool SBAND>
 __global__ __launch_bounds__(64) void pair_fill_kernel(const PairParams G) {
-  const int lane = threadIdx.x;
-  int32_t* const rowbuf = G.rowbuf + (size_t)blockIdx.x * 2 * G.row_stride;
-  for (;;) {
-    uint32_t pid = 0;
-    {
-        // The electing lane id is made opaque on every trip: with a plain `lane == 0` hipcc threads
-        // this branch together with a later `if (lane == 0)` of the previous trip, lane 0 then loops
-        // apart from lanes 1..63 and the readfirstlane below no longer sees lane 0 (observed: hang).
-        int elect = lane;
-        asm volatile("" : "+v"(elect));
-        if (elect == 0) pid = atomicAdd(G.queue, 1u);
-    }
-    pid = __builtin_amdgcn_readfirstlane(pid);
-    if (pid >= G.n_pairs) break;
-    const PairDesc P = G.pairs[pid];
-    const int n = P.n, m = P.m;
-    const int T = m + 63;
-    const int n_stripes = (n + 64 * RL - 1) / (64 * RL);
+    const int lane = threadIdx.x;
     const int match = G.match, mismatch = G.mismatch, gap = G.gap;
+    for (;;) {
+        uint32_t tid = 0;
+        {
+            // see batch_scores.hip.h: the electing lane id must be opaque on every trip
+            int elect = lane;
+            asm volatile("" : "+v"(elect));
+            if (elect == 0) tid = atomicAdd(G.queue, 1u);
+        }
+        tid = __builtin_amdgcn_readfirstlane(tid);
+        if (tid >= G.n_tasks) break;
+        const StripeTask task = G.tasks[tid];
+        const PairDesc P = G.pairs[task.pair];
+        const int s = (int)task.stripe;
+        const int n = P.n, m = P.m;
+        const int T = m + 63;
+        const int n_chunks = (T + 63) >> 6;
+        const bool has_top = s > 0;
+        const bool has_bot = (uint32_t)(s + 1) < P.n_stripes;
 
-    int bs[RL], bi[RL], bj[RL];   // SW: best per row slot
-#pragma unroll
-    for (int r = 0; r < RL; ++r) { bs[r] = 0; bi[r] = 0; bj[r] = 0; }
-
-    for (int s = 0; s < n_stripes; ++s) {
         const int i_first = s * 64 * RL + lane * RL + 1;   // first row of this lane (1-based)
-        int pc[RL], hl[RL];
+        int pc[RL], hl[RL], bs[RL], bj[RL];
 #pragma unroll
         for (int r = 0; r < RL; ++r) {
             const int i = i_first + r;
-            pc[r] = (i <= n) ? (int)P.pat[i - 1] : 256;                 // 256 never equals a text byte
-            hl[r] = LOCAL ? 0 : p_mulw(i, gap);                         // dp[i][0], hw2.cpp:125-130
+            pc[r] = (i <= n) ? (int)((g_cu8*)P.pat)[i - 1] : 256;   // 256 never equals a text byte
+            hl[r] = LOCAL ? 0 : p_mulw(i, gap);           // dp[i][0], hw2.cpp:125-130
+            bs[r] = 0;
+            bj[r] = 0;
         }
-        int diag0 = LOCAL ? 0 : p_mulw(i_first - 1, gap);               // dp[i_first-1][0]
-        const int32_t* rin = rowbuf + (size_t)((s + 1) & 1) * G.row_stride;
-        int32_t* rout = rowbuf + (size_t)(s & 1) * G.row_stride;
-        uint8_t* tbs = TB ? P.tb + (size_t)s * T * 64 * RL : nullptr;
-        int32_t* sbs = SBAND ? P.sband + (size_t)s * T * 64 * RL : nullptr;
+        int diag0 = LOCAL ? 0 : p_mulw(i_first - 1, gap);   // dp[i_first-1][0]
+        g_i32* rin = (g_i32*)(P.rows + (size_t)(has_top ? s - 1 : 0) * P.row_stride);
+        g_i32* rout = (g_i32*)(P.rows + (size_t)s * P.row_stride);
+        g_u8* tbs = TB ? (g_u8*)(P.tb + (size_t)s * T * 64 * RL) : nullptr;
+        g_i32* sbs = SBAND ? (g_i32*)(P.sband + (size_t)s * T * 64 * RL) : nullptr;
+        g_cu8* txt = (g_cu8*)P.txt;
+        PWA_GLOBAL PairResult* res = (PWA_GLOBAL PairResult*)P.res;
+        g_u32* prog_in = (g_u32*)(G.progress + (has_top ? tid - 1 : tid));   // previous stripe of the same pair
+        g_u32* prog_out = (g_u32*)(G.progress + tid);
 
-        int bottom = 0, tch = 0;   // this lane's last-row value / text char of the previous step
-        int topv = 0, tcv = 0;     // staged: top-row value and text char of column t0 + lane
-        int collect = 0;           // bottom row of the stripe, column (t - 63), gathered by lane
-        for (int t = 0; t < T; ++t) {
-            if ((t & 63) == 0) {
-                const int c = t + lane;
-                if (c < m) {
-                    tcv = P.txt[c];
-                    topv = (s == 0) ? (LOCAL ? 0 : p_mulw(c + 1, gap)) : rin[c];   // dp[row above][c+1]
-                }
-            }
-            const int q = t & 63;
-            const int top_c = __builtin_amdgcn_readlane(topv, q);
-            const int txt_c = __builtin_amdgcn_readlane(tcv, q);
-            const int up_in = wave_shr1(top_c, bottom);   // dp[i_first-1][j]
-            tch = wave_shr1(txt_c, tch);
-            const int c = t - lane;
-            uint32_t codes = 0;
-            int hnew[RL];
-            if (c >= 0 && c < m) {
-                const int j = c + 1;
-                int dg = diag0, up = up_in;
-#pragma unroll
-                for (int r = 0; r < RL; ++r) {
-                    const int sc = (pc[r] == tch) ? match : mismatch;
-                    const int tdiag = p_addw(dg, sc);
-                    const int lf = hl[r];
-                    const int ug = p_addw(up, gap), lg = p_addw(lf, gap);
-                    int h, code;
-                    if (LOCAL) {
-                        h = max(0, max(tdiag, max(ug, lg)));                       // hw2.cpp:211
-                        code = (h == 0) ? TB_STOP : (h == tdiag) ? TB_DIAG : (h == ug) ? TB_UP : TB_LEFT;   // 214-222
-                        if (h > bs[r] && (i_first + r) <= n) {                    // hw2.cpp:225-229
-                            bs[r] = h;
-                            bi[r] = i_first + r;
-                            bj[r] = j;
-                        }
-                    } else {
-                        h = tdiag;                                                 // hw2.cpp:142-153
-                        code = TB_DIAG;
-                        if (lg > h) { h = lg; code = TB_LEFT; }
-                        if (ug > h) { h = ug; code = TB_UP; }
-                        if ((i_first + r) == n && j == m) P.res->score = h;      // hw2.cpp:186
-                    }
-                    codes |= (uint32_t)code << (8 * r);
-                    dg = lf;
-                    up = h;
-                    hl[r] = h;
-                    hnew[r] = h;
-                }
-                diag0 = up_in;
-                bottom = up;
-            } else {
-#pragma unroll
-                for (int r = 0; r < RL; ++r) hnew[r] = 0;
-            }
-            // ---- traceback band: 64*RL contiguous bytes per step
-            if (!TB) {
-            } else if (RL == 4) {
-                reinterpret_cast<uint32_t*>(tbs)[(size_t)t * 64 + lane] = codes;
-            } else {
-#pragma unroll
-                for (int r = 0; r < RL; ++r) tbs[((size_t)t * 64 + lane) * RL + r] = (uint8_t)(codes >> (8 * r));
-            }
-            if (SBAND) {
-#pragma unroll
-                for (int r = 0; r < RL; ++r) sbs[((size_t)t * 64 + lane) * RL + r] = hnew[r];
-            }
-            // ---- bottom row of the stripe: lane 63 finished column t-63 in this step
+        int bottom = 0, tch = 0, coll = 0;
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const int t0 = ch << 6;
+            // ---- stage the row above the stripe and the text for columns t0 .. t0+63
+            int topv = 0, tcv = 0;
             {
-                const int b63 = __builtin_amdgcn_readlane(bottom, 63);
-                const int cc = t - 63;
-                if (cc >= 0 && lane == (cc & 63)) collect = b63;
-                if (cc >= 0 && ((cc & 63) == 63 || cc == m - 1)) {
-                    const int c0 = cc & ~63;
-                    if (c0 + lane <= cc) rout[c0 + lane] = collect;
+                const int c = t0 + lane;
+                if (has_top) {
+                    const uint32_t need = (uint32_t)min(ch + 2, n_chunks);
+                    uint32_t spins = 0;
+                    while (__hip_atomic_load(prog_in, PWA_RLX_AGENT) < need) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > (1u << 24)) {   // bounded spin: flag the failure and go on with junk
+                            if (lane == 0) __hip_atomic_store((g_u32*)(G.queue + 1), 1u, PWA_RLX_AGENT);
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only: row loads stay below the poll
+                    if (c < m) topv = __hip_atomic_load(rin + c, PWA_RLX_AGENT);   // sc1 load
+                } else if (!LOCAL) {
+                    topv = p_mulw(c + 1, gap);   // dp[0][j], hw2.cpp:131-136
                 }
+                if (c < m) tcv = txt[c];
+            }
+            const bool interior = t0 >= 63 && t0 + 64 < m;   // every lane inside the matrix, last column not touched
+            if (interior) {
+#pragma unroll 4
+                for (int q = 0; q < 64; ++q)
+                    stripe_step<RL, LOCAL, TB, SBAND, false>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
+                                                             tcv, coll, bs, bj, match, mismatch, gap, tbs, sbs, res);
+            } else {
+                const int qn = min(64, T - t0);
+#pragma unroll 1
+                for (int q = 0; q < qn; ++q)
+                    stripe_step<RL, LOCAL, TB, SBAND, true>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
+                                                            tcv, coll, bs, bj, match, mismatch, gap, tbs, sbs, res);
+#pragma unroll 1
+                for (int q = qn; q < 64; ++q) coll = wave_shl1(bottom, coll);   // keep the collector aligned
+            }
+            // ---- publish the bottom row: after the chunk lane l holds column t0 - 63 + l
+            if (has_bot) {
+                const int c = t0 - 63 + lane;
+                if (c >= 0 && c < m) __hip_atomic_store(rout + c, coll, PWA_RLX_AGENT);   // sc1 (write-through) store
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // drain before the flag
+                if (lane == 0) __hip_atomic_store(prog_out, (uint32_t)(ch + 1), PWA_RLX_AGENT);
+            }
+        }
+
+        if (LOCAL) {
+            // per-lane reduction over row slots, then over the wave: max score, then smallest i
+            int s_best = 0, i_best = 0, j_best = 0;
+#pragma unroll
+            for (int r = 0; r < RL; ++r) {
+                const int i = i_first + r;
+                if (i <= n && bs[r] > s_best) {   // slots in increasing i: strict '>' keeps the smallest i
+                    s_best = bs[r];
+                    i_best = i;
+                    j_best = bj[r];
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const int so = __shfl_xor(s_best, off), io = __shfl_xor(i_best, off), jo = __shfl_xor(j_best, off);
+                const bool better = so > s_best || (so == s_best && so > 0 && io < i_best);
+                if (better) { s_best = so; i_best = io; j_best = jo; }
+            }
+            int wr = lane;
+            asm volatile("" : "+v"(wr));   // opaque for the same reason as `elect` above
+            if (wr == 0) {
+                g_i32* bp = (g_i32*)(G.best + tid);
+                bp[0] = s_best;
+                bp[1] = i_best;
+                bp[2] = j_best;
+                bp[3] = 0;
             }
         }
     }
-
-    if (LOCAL) {
-        // per-lane reduction over row slots, then over the wave: max score, then smallest i
-        int s_best = bs[0], i_best = bi[0], j_best = bj[0];
-#pragma unroll
-        for (int r = 1; r < RL; ++r) {
-            const bool better = bs[r] > s_best || (bs[r] == s_best && bs[r] > 0 && bi[r] < i_best);
-            if (better) { s_best = bs[r]; i_best = bi[r]; j_best = bj[r]; }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const int so = __shfl_xor(s_best, off), io = __shfl_xor(i_best, off), jo = __shfl_xor(j_best, off);
-            const bool better = so > s_best || (so == s_best && so > 0 && io < i_best);
-            if (better) { s_best = so; i_best = io; j_best = jo; }
-        }
-        if (lane == 0) {
-            P.res->score = s_best;
-            P.res->end_i = (uint32_t)i_best;
-            P.res->end_j = (uint32_t)j_best;
-        }
-    } else if (lane == 0) {
-        P.res->end_i = (uint32_t)n;
-        P.res->end_j = (uint32_t)m;
-    }
-  }
 }
 
-// Walk of hw2.cpp:163-181 (NW) / 239-257 (SW) over the skewed band.  One lane per pair: a walk
-// is a dependent chain of n+m byte reads.
-template <int RL, bool LOCAL>
+// Picks the walk's start cell, then walks hw2.cpp:163-181 (NW) / 239-257 (SW) over the skewed band.
+// One wavefront per pair.  The walk is a dependent chain of n+m one-byte reads, but it only ever
+// moves BACKWARDS through the band, at most two steps (512 B) per op and always inside one stripe
+// until it crosses into the stripe above.  So the wave stages a window of WIN consecutive steps of
+// the current stripe (WIN x 256 B, contiguous in HBM thanks to the skewed layout) into LDS with
+// coalesced 1 KiB loads and walks inside LDS; the walk state is wave-uniform and lives in SGPRs.
+template <int RL, bool LOCAL, bool WALK>
 __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) {
-    const uint32_t pid = blockIdx.x * 64 + threadIdx.x;
+    constexpr int WIN = 128;                       // steps per LDS window
+    constexpr int STEP_BYTES = 64 * RL;
+    __shared__ __attribute__((aligned(16))) uint8_t win[WALK ? WIN * STEP_BYTES : 16];
+    const int lane = threadIdx.x;
+    const uint32_t pid = blockIdx.x;
     if (pid >= G.n_pairs) return;
     const PairDesc P = G.pairs[pid];
     const int m = P.m;
-    int i = (int)P.res->end_i, j = (int)P.res->end_j;
+    const size_t T = (size_t)m + 63;
+    g_cu8* tb = (g_cu8*)P.tb;
+    g_u8* ops = (g_u8*)P.ops;
+    PWA_GLOBAL PairResult* res = (PWA_GLOBAL PairResult*)P.res;
+    int i, j;
+    if (LOCAL) {
+        int sb = 0;
+        i = 0;
+        j = 0;
+        for (uint32_t s = 0; s < P.n_stripes; ++s) {   // stripes in increasing i: strict '>' = first row-major maximum
+            const PWA_GLOBAL StripeBest* b = (const PWA_GLOBAL StripeBest*)(G.best + P.first_task + s);
+            const int sc = b->score;
+            if (sc > sb) {
+                sb = sc;
+                i = (int)b->i;
+                j = (int)b->j;
+            }
+        }
+        if (lane == 0) res->score = sb;
+    } else {
+        i = P.n;
+        j = P.m;
+    }
+    i = __builtin_amdgcn_readfirstlane(i);
+    j = __builtin_amdgcn_readfirstlane(j);
+    if (lane == 0) {
+        res->end_i = (uint32_t)i;
+        res->end_j = (uint32_t)j;
+    }
+    if (!WALK) return;
     uint32_t cnt = 0, overflow = 0;
+    int ws = -1, t_lo = 0, t_hi = -1;              // window: steps [t_lo, t_hi] of stripe ws
     for (;;) {
         int code;
-        if (LOCAL) {
-            if (!(i > 0 && j > 0)) break;                       // hw2.cpp:239
-            code = P.tb[tb_index<RL>(i, j, m)];
-            if (code == TB_STOP) break;                         // dp == 0
+        if (LOCAL ? !(i > 0 && j > 0) : !(i > 0 || j > 0)) break;       // hw2.cpp:239 / 163
+        if (i > 0 && j > 0) {
+            const int q = i - 1;
+            const int s = q / (64 * RL), k = (q % (64 * RL)) / RL, r = q % RL;
+            const int t = j - 1 + k;
+            if (s != ws || t < t_lo || t > t_hi) {                      // (re)stage the window ending at step t
+                ws = s;
+                t_hi = t;
+                t_lo = max(0, t - (WIN - 1));
+                const g_cu8* src = tb + ((size_t)s * T + (size_t)t_lo) * STEP_BYTES;
+                const int nbytes = (t_hi - t_lo + 1) * STEP_BYTES;
+                __syncthreads();
+                // 8 independent 1 KiB loads in flight per batch (a load-wait-write loop would pay the
+                // full HBM latency 32 times per window)
+                for (int base = 0; base < nbytes; base += 8 * 1024) {
+                    u32x4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int o = base + u * 1024 + lane * 16;
+                        v[u] = (o < nbytes) ? *reinterpret_cast<const PWA_GLOBAL u32x4*>(src + o) : u32x4{0, 0, 0, 0};
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int o = base + u * 1024 + lane * 16;
+                        if (o < nbytes) *reinterpret_cast<u32x4*>(win + o) = v[u];
+                    }
+                }
+                __syncthreads();
+            }
+            code = win[((t - t_lo) * 64 + k) * RL + r];
+            code = __builtin_amdgcn_readfirstlane(code);
+            if (LOCAL && code == TB_STOP) break;                        // dp == 0
         } else {
-            if (!(i > 0 || j > 0)) break;                       // hw2.cpp:163
-            if (i > 0 && j > 0) code = P.tb[tb_index<RL>(i, j, m)];
-            else code = (i > 0) ? TB_UP : TB_LEFT;              // hw2.cpp:125-136: column 0 'u', row 0 'l'
+            code = (i > 0) ? TB_UP : TB_LEFT;                           // hw2.cpp:125-136: column 0 'u', row 0 'l'
         }
         uint8_t op;
-        if (code == TB_DIAG) { op = 'M'; --i; --j; }            // hw2.cpp:164-169 / 240-245
-        else if (code == TB_UP) { op = 'D'; --i; }              // hw2.cpp:170-174 / 246-250
-        else { op = 'I'; --j; }                                 // hw2.cpp:175-179 / 251-255
-        if (cnt < P.ops_cap) P.ops[cnt] = op; else overflow = 1;
+        if (code == TB_DIAG) { op = 'M'; --i; --j; }                    // hw2.cpp:164-169 / 240-245
+        else if (code == TB_UP) { op = 'D'; --i; }                      // hw2.cpp:170-174 / 246-250
+        else { op = 'I'; --j; }                                         // hw2.cpp:175-179 / 251-255
+        if (cnt < P.ops_cap) {
+            if (lane == 0) ops[cnt] = op;
+        } else {
+            overflow = 1;
+        }
         ++cnt;
     }
-    P.res->start_i = (uint32_t)i;
-    P.res->start_j = (uint32_t)j;
-    P.res->n_ops = cnt;
-    P.res->overflow = overflow;
+    if (lane == 0) {
+        res->start_i = (uint32_t)i;
+        res->start_j = (uint32_t)j;
+        res->n_ops = cnt;
+        res->overflow = overflow;
+    }
 }
 
 }  // namespace pwa

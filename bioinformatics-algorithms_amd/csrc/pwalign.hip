@@ -81,6 +81,7 @@ struct BatchKernelEntry {
 };
 #define BK(R, M, S) {R, M, S, batch_scores_kernel<R, M, S>, "batch_scores_kernel<R=" #R "," #M "," #S ">"}
 const BatchKernelEntry kBatchKernels[] = {
+    BK(76, BM_SW, SC_PERM),   BK(104, BM_SW, SC_PERM),
     BK(64, BM_SW, SC_PERM),   BK(128, BM_SW, SC_PERM),  BK(152, BM_SW, SC_PERM),
     BK(64, BM_SW, SC_CMP),    BK(128, BM_SW, SC_CMP),   BK(152, BM_SW, SC_CMP),
     BK(64, BM_NW, SC_PERM),   BK(128, BM_NW, SC_PERM),  BK(152, BM_NW, SC_PERM),
@@ -89,7 +90,6 @@ const BatchKernelEntry kBatchKernels[] = {
     BK(64, BM_NWG, SC_CMP),   BK(128, BM_NWG, SC_CMP),  BK(152, BM_NWG, SC_CMP),
 };
 #undef BK
-const int kStripRows[] = {64, 128, 152};
 
 const BatchKernelEntry* find_batch_kernel(int R, int mode, int score) {
     for (const auto& e : kBatchKernels)
@@ -108,14 +108,85 @@ pair_kernel_t pair_fill_fn(bool local, bool tb, bool sband) {
     if (tb) return sband ? pair_fill_kernel<kRL, false, true, true> : pair_fill_kernel<kRL, false, true, false>;
     return pair_fill_kernel<kRL, false, false, false>;
 }
-pair_kernel_t pair_tb_fn(bool local) {
-    return local ? pair_traceback_kernel<kRL, true> : pair_traceback_kernel<kRL, false>;
+pair_kernel_t pair_tb_fn(bool local, bool walk) {
+    if (local) return walk ? pair_traceback_kernel<kRL, true, true> : pair_traceback_kernel<kRL, true, false>;
+    return walk ? pair_traceback_kernel<kRL, false, true> : pair_traceback_kernel<kRL, false, false>;
 }
 
 size_t tb_band_bytes(uint64_t n, uint64_t m) {
     const uint64_t stripes = (n + 64 * kRL - 1) / (64 * kRL);
     return (size_t)(stripes * (m + 63) * 64 * kRL);
 }
+
+// Device-side state of one launch of the wavefront (pair) engine: pair descriptors, the global
+// stripe-task list, hand-off rows, progress counters, per-stripe bests.
+struct PairLaunch {
+    DevBuf desc, tasks, rows, progress, best, queue;
+    PairParams G{};
+    uint32_t grid = 0;
+    uint64_t row_bytes = 0;
+
+    // pd[q].{pat,txt,n,m,tb,sband,res,ops,ops_cap} filled by the caller; this adds the pipeline fields
+    int build(pwa_ctx* ctx, std::vector<PairDesc>& pd, int match, int mismatch, int gap) {
+        std::vector<StripeTask> tl;
+        uint64_t rows_i32 = 0;
+        for (size_t q = 0; q < pd.size(); ++q) {
+            const uint64_t ns = ((uint64_t)pd[q].n + 64 * kRL - 1) / (64 * kRL);
+            if (tl.size() + ns >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "too many stripe tasks in one launch");
+            pd[q].first_task = (uint32_t)tl.size();
+            pd[q].n_stripes = (uint32_t)ns;
+            pd[q].row_stride = (uint32_t)align_up((uint64_t)pd[q].m + 64, 64);
+            for (uint64_t st = 0; st < ns; ++st) tl.push_back({(uint32_t)q, (uint32_t)st});
+            rows_i32 += (ns - 1) * pd[q].row_stride;
+        }
+        row_bytes = rows_i32 * sizeof(int32_t);
+        HIPC(ctx, rows.alloc(row_bytes));
+        uint64_t ro = 0;
+        for (auto& d : pd) {
+            d.rows = rows.as<int32_t>() + ro;
+            ro += (uint64_t)(d.n_stripes - 1) * d.row_stride;
+        }
+        HIPC(ctx, desc.alloc(pd.size() * sizeof(PairDesc)));
+        HIPC(ctx, hipMemcpy(desc.p, pd.data(), pd.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
+        HIPC(ctx, tasks.alloc(tl.size() * sizeof(StripeTask)));
+        HIPC(ctx, hipMemcpy(tasks.p, tl.data(), tl.size() * sizeof(StripeTask), hipMemcpyHostToDevice));
+        HIPC(ctx, progress.alloc(align_up(tl.size() * sizeof(uint32_t), 16)));
+        HIPC(ctx, best.alloc(tl.size() * sizeof(StripeBest)));
+        HIPC(ctx, queue.alloc(64));
+        G.pairs = desc.as<PairDesc>();
+        G.tasks = tasks.as<StripeTask>();
+        G.n_pairs = (uint32_t)pd.size();
+        G.n_tasks = (uint32_t)tl.size();
+        G.queue = queue.as<uint32_t>();
+        G.progress = progress.as<uint32_t>();
+        G.best = best.as<StripeBest>();
+        G.match = match;
+        G.mismatch = mismatch;
+        G.gap = gap;
+        // Tasks come off the queue in global order, so correctness does not depend on how many waves are
+        // resident; 8 single-wave workgroups per CU keep every SIMD at two waves.
+        grid = (uint32_t)std::min<uint64_t>(tl.size(), (uint64_t)ctx->num_cu * 8);
+        return PWA_OK;
+    }
+    // enqueue: zero the queue / progress words, fill, then the walk (or only the end-cell pick)
+    int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, bool walk, hipEvent_t after_fill) {
+        HIPC(ctx, hipMemsetAsync(queue.p, 0, 16, st));
+        HIPC(ctx, hipMemsetAsync(progress.p, 0, progress.bytes, st));
+        hipLaunchKernelGGL(pair_fill_fn(local, tb, false), dim3(grid), dim3(64), 0, st, G);
+        HIPC(ctx, hipGetLastError());
+        if (after_fill) HIPC(ctx, hipEventRecord(after_fill, st));
+        hipLaunchKernelGGL(pair_tb_fn(local, walk), dim3(G.n_pairs), dim3(64), 0, st, G);   // one wave per pair
+        HIPC(ctx, hipGetLastError());
+        return PWA_OK;
+    }
+    // after the stream has been synchronised: did a bounded spin give up?
+    int check(pwa_ctx* ctx) {
+        uint32_t q[2] = {0, 0};
+        HIPC(ctx, hipMemcpy(q, queue.p, sizeof q, hipMemcpyDeviceToHost));
+        if (q[1] != 0) return fail(ctx, PWA_E_HIP, "stripe pipeline timed out waiting for the stripe above");
+        return PWA_OK;
+    }
+};
 
 }  // namespace
 
@@ -133,9 +204,8 @@ struct pwa_batch {
     uint32_t grid = 0;
     DevBuf arena, tasks, slot_poff, slot_plen, slot_out, hand, queue, scores;
     // engine 2: wavefront kernels without traceback band (exact end cells, any scoring)
-    PairParams pp{};
-    DevBuf pair_desc, pair_res, rowbuf;
-    uint32_t pair_grid = 0;
+    PairLaunch pl;
+    DevBuf pair_res;
     uint64_t n_live = 0;            // pairs that reach a kernel (n > 0 and m > 0)
     std::vector<uint32_t> live_idx; // engine 2: pair index of descriptor k
     std::vector<int32_t> host_scores;   // trivial pairs resolved on the host
@@ -367,16 +437,21 @@ int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, c
             p = q;
         }
         // ---- strip height: least padded work, ties to the taller strip
-        int bestR = kStripRows[0];
+        int bestR = 0;
         long double best_cost = -1;
-        for (int R : kStripRows) {
+        const char* force = std::getenv("PWA_FORCE_R");   // experiments only
+        for (const auto& e : kBatchKernels) {
+            if (e.mode != kmode || e.score != score_path) continue;
+            const int R = e.R;
+            if (force && std::atoi(force) != R) continue;
             long double cost = 0;
             for (const auto& t : ht) cost += (long double)((t.maxlen + R - 1) / R * R) * (long double)slen(t.text) * 64.0L;
-            if (best_cost < 0 || cost <= best_cost) {
+            if (best_cost < 0 || cost < best_cost || (cost == best_cost && R > bestR)) {
                 best_cost = cost;
                 bestR = R;
             }
         }
+        if (bestR == 0) return fail(ctx, PWA_E_INVALID, "internal: no kernel instantiation");
         const int R = bestR;
         b->padded_cells = (uint64_t)best_cost;
         b->kern = find_batch_kernel(R, kmode, score_path);
@@ -460,19 +535,10 @@ int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, c
             const uint64_t n = slen(pair_a[k]), m = slen(pair_b[k]);
             b->padded_cells += (n + 64 * kRL - 1) / (64 * kRL) * (64 * kRL) * m;
         }
-        HIPC(ctx, b->pair_desc.alloc(nl * sizeof(PairDesc)));
-        HIPC(ctx, hipMemcpy(b->pair_desc.p, pd.data(), nl * sizeof(PairDesc), hipMemcpyHostToDevice));
-        b->pair_grid = (uint32_t)std::min<uint64_t>(nl, (uint64_t)ctx->num_cu * 16);
-        const uint64_t stride = align_up(max_m + 64, 64);
-        HIPC(ctx, b->rowbuf.alloc((size_t)b->pair_grid * 2 * stride * sizeof(int32_t)));
-        b->pp.pairs = b->pair_desc.as<PairDesc>();
-        b->pp.n_pairs = (uint32_t)nl;
-        b->pp.queue = b->queue.as<uint32_t>();
-        b->pp.rowbuf = b->rowbuf.as<int32_t>();
-        b->pp.row_stride = stride;
-        b->pp.match = match;
-        b->pp.mismatch = mismatch;
-        b->pp.gap = gap;
+        {
+            const int rc = b->pl.build(ctx, pd, match, mismatch, gap);
+            if (rc != PWA_OK) return rc;
+        }
         b->kernel_name = local ? "pair_fill_kernel<RL=4,SW,no-traceback>" : "pair_fill_kernel<RL=4,NW,no-traceback>";
     }
     guard.b = nullptr;
@@ -487,13 +553,14 @@ int pwa_batch_run(pwa_batch* b, void* stream_v) {
     const int slot = (int)(b->n_runs % pwa_batch::kRing);
     HIPC(ctx, hipEventRecord(b->ev0[slot], st));
     if (b->n_live) {
-        HIPC(ctx, hipMemsetAsync(b->queue.p, 0, 16, st));
         if (b->use_strips) {
+            HIPC(ctx, hipMemsetAsync(b->queue.p, 0, 16, st));
             hipLaunchKernelGGL(b->kern->fn, dim3(b->grid), dim3(64), 0, st, b->bp);
+            HIPC(ctx, hipGetLastError());
         } else {
-            hipLaunchKernelGGL(pair_fill_fn(b->mode == PWA_MODE_SW, false, false), dim3(b->pair_grid), dim3(64), 0, st, b->pp);
+            const int rc = b->pl.launch(ctx, st, b->mode == PWA_MODE_SW, false, false, nullptr);
+            if (rc != PWA_OK) return rc;
         }
-        HIPC(ctx, hipGetLastError());
     }
     HIPC(ctx, hipEventRecord(b->ev1[slot], st));
     ++b->n_runs;
@@ -547,6 +614,10 @@ int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint3
             if (end_j_out) std::memcpy(end_j_out, b->host_end_j.data(), b->n_pairs * 4);
         }
         return PWA_OK;
+    }
+    {
+        const int rc = b->pl.check(ctx);
+        if (rc != PWA_OK) return rc;
     }
     std::vector<PairResult> res(b->n_live);
     HIPC(ctx, hipMemcpy(res.data(), b->pair_res.p, b->n_live * sizeof(PairResult), hipMemcpyDeviceToHost));
@@ -649,14 +720,13 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
         const uint64_t nc = k1 - k0;
         if (band + opsb > budget && nc == 1 && band + opsb > (uint64_t)(free_b * 0.97))
             return fail(ctx, PWA_E_NOMEM, "traceback band of a single pair exceeds free HBM");
-        DevBuf d_band, d_ops, d_res, d_desc, d_rows, d_queue;
+        DevBuf d_band, d_ops, d_res;
+        PairLaunch pl;
         HIPC(ctx, d_band.alloc(band));
         HIPC(ctx, d_ops.alloc(opsb));
         HIPC(ctx, d_res.alloc(nc * sizeof(PairResult)));
-        HIPC(ctx, d_queue.alloc(64));
         std::vector<PairResult> res(nc);
         std::vector<PairDesc> pd;
-        std::vector<uint32_t> live;   // index into chunk
         std::vector<uint64_t> ooff(nc);
         uint64_t bo = 0, oo = 0;
         for (uint64_t q = 0; q < nc; ++q) {
@@ -675,7 +745,6 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
                 d.ops = d_ops.as<uint8_t>() + oo;
                 d.ops_cap = (uint32_t)std::min<uint64_t>(n + m, 0xffffffffu);
                 pd.push_back(d);
-                live.push_back((uint32_t)q);
                 bo += align_up(tb_band_bytes(n, m), 256);
                 ctx->band_bytes += tb_band_bytes(n, m);
             } else if (!local) {
@@ -687,37 +756,19 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
         }
         HIPC(ctx, hipMemcpy(d_res.p, res.data(), nc * sizeof(PairResult), hipMemcpyHostToDevice));
         if (!pd.empty()) {
-            HIPC(ctx, d_desc.alloc(pd.size() * sizeof(PairDesc)));
-            HIPC(ctx, hipMemcpy(d_desc.p, pd.data(), pd.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
-            PairParams G;
-            std::memset(&G, 0, sizeof G);
-            G.pairs = d_desc.as<PairDesc>();
-            G.n_pairs = (uint32_t)pd.size();
-            G.queue = d_queue.as<uint32_t>();
-            const uint32_t grid = (uint32_t)std::min<uint64_t>(pd.size(), (uint64_t)ctx->num_cu * 16);
-            G.row_stride = align_up(max_m + 64, 64);
-            HIPC(ctx, d_rows.alloc((size_t)grid * 2 * G.row_stride * sizeof(int32_t)));
-            G.rowbuf = d_rows.as<int32_t>();
-            G.match = match;
-            G.mismatch = mismatch;
-            G.gap = gap;
-            HIPC(ctx, hipMemsetAsync(d_queue.p, 0, 16, ctx->stream));
-            HIPC(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+            int rc = pl.build(ctx, pd, match, mismatch, gap);
+            if (rc != PWA_OK) return rc;
             const bool dbg = std::getenv("PWA_DEBUG") != nullptr;
-            if (dbg) std::fprintf(stderr, "[pwa] fill launch grid=%u pairs=%u stride=%llu band=%llu\n", grid, G.n_pairs,
-                                  (unsigned long long)G.row_stride, (unsigned long long)band);
-            hipLaunchKernelGGL(pair_fill_fn(local, true, false), dim3(grid), dim3(64), 0, ctx->stream, G);
-            HIPC(ctx, hipGetLastError());
-            HIPC(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-            if (dbg) {
-                HIPC(ctx, hipStreamSynchronize(ctx->stream));
-                std::fprintf(stderr, "[pwa] fill done\n");
-            }
-            hipLaunchKernelGGL(pair_tb_fn(local), dim3((G.n_pairs + 63) / 64), dim3(64), 0, ctx->stream, G);
-            HIPC(ctx, hipGetLastError());
+            if (dbg) std::fprintf(stderr, "[pwa] fill launch grid=%u pairs=%u tasks=%u band=%llu rows=%llu\n", pl.grid,
+                                  pl.G.n_pairs, pl.G.n_tasks, (unsigned long long)band, (unsigned long long)pl.row_bytes);
+            HIPC(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+            rc = pl.launch(ctx, ctx->stream, local, true, true, ctx->ev[1]);
+            if (rc != PWA_OK) return rc;
             HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
             HIPC(ctx, hipStreamSynchronize(ctx->stream));
-            if (dbg) std::fprintf(stderr, "[pwa] traceback done\n");
+            if (dbg) std::fprintf(stderr, "[pwa] fill + traceback done\n");
+            rc = pl.check(ctx);
+            if (rc != PWA_OK) return rc;
             float a = 0, c = 0;
             HIPC(ctx, hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
             HIPC(ctx, hipEventElapsedTime(&c, ctx->ev[1], ctx->ev[2]));
