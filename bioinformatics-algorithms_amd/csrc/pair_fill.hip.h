@@ -302,14 +302,17 @@ __global__ __launch_bounds__(64) void pair_fill_kernel(const PairParams G) {
 // Picks the walk's start cell, then walks hw2.cpp:163-181 (NW) / 239-257 (SW) over the skewed band.
 // One wavefront per pair.  The walk is a dependent chain of n+m one-byte reads, but it only ever
 // moves BACKWARDS through the band, at most two steps (512 B) per op and always inside one stripe
-// until it crosses into the stripe above.  So the wave stages a window of WIN consecutive steps of
-// the current stripe (WIN x 256 B, contiguous in HBM thanks to the skewed layout) into LDS with
-// coalesced 1 KiB loads and walks inside LDS; the walk state is wave-uniform and lives in SGPRs.
+// until it crosses into the stripe above.  So the band is consumed in windows of WIN consecutive
+// steps (WIN x 256 B, contiguous in HBM thanks to the skewed layout), staged into LDS by LDS-DMA
+// (global_load_lds, 1 KiB per instruction, no VGPR round trip); while the walk runs inside one
+// window the window before it is already in flight into the second LDS buffer.  The walk state
+// is wave-uniform and lives in SGPRs; the only per-op latency left is one ds_read_u8.
 template <int RL, bool LOCAL, bool WALK>
 __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) {
-    constexpr int WIN = 128;                       // steps per LDS window
+    constexpr int WIN = 64;                        // steps per LDS window
     constexpr int STEP_BYTES = 64 * RL;
-    __shared__ __attribute__((aligned(16))) uint8_t win[WALK ? WIN * STEP_BYTES : 16];
+    constexpr int WB = WIN * STEP_BYTES;           // bytes per window (16 KiB for RL = 4)
+    __shared__ __attribute__((aligned(16))) uint8_t win[WALK ? 2 * WB : 16];
     const int lane = threadIdx.x;
     const uint32_t pid = blockIdx.x;
     if (pid >= G.n_pairs) return;
@@ -345,61 +348,89 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         res->end_j = (uint32_t)j;
     }
     if (!WALK) return;
-    uint32_t cnt = 0, overflow = 0;
-    int ws = -1, t_lo = 0, t_hi = -1;              // window: steps [t_lo, t_hi] of stripe ws
-    for (;;) {
-        int code;
-        if (LOCAL ? !(i > 0 && j > 0) : !(i > 0 || j > 0)) break;       // hw2.cpp:239 / 163
-        if (i > 0 && j > 0) {
-            const int q = i - 1;
-            const int s = q / (64 * RL), k = (q % (64 * RL)) / RL, r = q % RL;
-            const int t = j - 1 + k;
-            if (s != ws || t < t_lo || t > t_hi) {                      // (re)stage the window ending at step t
-                ws = s;
-                t_hi = t;
-                t_lo = max(0, t - (WIN - 1));
-                const g_cu8* src = tb + ((size_t)s * T + (size_t)t_lo) * STEP_BYTES;
-                const int nbytes = (t_hi - t_lo + 1) * STEP_BYTES;
-                __syncthreads();
-                // 8 independent 1 KiB loads in flight per batch (a load-wait-write loop would pay the
-                // full HBM latency 32 times per window)
-                for (int base = 0; base < nbytes; base += 8 * 1024) {
-                    u32x4 v[8];
+    // LDS-DMA of window w of stripe s into buffer `buf`: 1 KiB per instruction.  A window may run past
+    // the end of its stripe or of the band; the host pads the band allocation by one window.
+    auto issue = [&](int buf, int s, int w) {
+        const size_t off0 = ((size_t)s * T + (size_t)w * WIN) * STEP_BYTES;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int o = base + u * 1024 + lane * 16;
-                        v[u] = (o < nbytes) ? *reinterpret_cast<const PWA_GLOBAL u32x4*>(src + o) : u32x4{0, 0, 0, 0};
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int o = base + u * 1024 + lane * 16;
-                        if (o < nbytes) *reinterpret_cast<u32x4*>(win + o) = v[u];
-                    }
+        for (int u = 0; u < WB / 1024; ++u)
+            __builtin_amdgcn_global_load_lds((const PWA_GLOBAL uint32_t*)(tb + off0 + (size_t)u * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) uint32_t*)(win + buf * WB + u * 1024), 16, 0, 0);
+    };
+    // ---- the walk.  Per trip the 64 lanes look at the 64 cells of the DIAGONAL through (i, j):
+    // lane d reads the code of (i-d, j-d).  The leading run of 'd' codes is one run of 'M' ops,
+    // emitted by the lanes in parallel; the first non-'d' code behind it is handled in the same
+    // trip.  (Typical alignments are mostly diagonal moves, so a trip retires several ops for the
+    // price of one LDS round trip.)
+    uint32_t cnt = 0;
+    int cb = 0, cur_s = -1, cur_w = -1, pre_s = -1, pre_w = -1;
+    bool stopped = false;
+    while (i > 0 && j > 0) {
+        {   // make sure the window holding (i, j) is staged (wave-uniform)
+            const unsigned q0 = (unsigned)(i - 1);
+            const int s0 = (int)(q0 / (64 * RL)), k0 = (int)((q0 % (64 * RL)) / RL);
+            const int w0 = (j - 1 + k0) / WIN;
+            if (s0 != cur_s || w0 != cur_w) {
+                if (s0 == pre_s && w0 == pre_w) cb ^= 1;                 // already in flight into the other buffer
+                else issue(cb, s0, w0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // LDS-DMA is ordered for our ds_read by vmcnt
+                cur_s = s0;
+                cur_w = w0;
+                pre_s = -1;
+                if (w0 > 0) {                                            // the walk only moves backwards
+                    issue(cb ^ 1, s0, w0 - 1);
+                    pre_s = s0;
+                    pre_w = w0 - 1;
                 }
-                __syncthreads();
             }
-            code = win[((t - t_lo) * 64 + k) * RL + r];
-            code = __builtin_amdgcn_readfirstlane(code);
-            if (LOCAL && code == TB_STOP) break;                        // dp == 0
-        } else {
-            code = (i > 0) ? TB_UP : TB_LEFT;                           // hw2.cpp:125-136: column 0 'u', row 0 'l'
         }
-        uint8_t op;
-        if (code == TB_DIAG) { op = 'M'; --i; --j; }                    // hw2.cpp:164-169 / 240-245
-        else if (code == TB_UP) { op = 'D'; --i; }                      // hw2.cpp:170-174 / 246-250
-        else { op = 'I'; --j; }                                         // hw2.cpp:175-179 / 251-255
-        if (cnt < P.ops_cap) {
-            if (lane == 0) ops[cnt] = op;
-        } else {
-            overflow = 1;
+        const int ii = i - lane, jj = j - lane;
+        int code = 0xff;                                                 // 0xff: not available in this trip
+        if (ii > 0 && jj > 0) {
+            const unsigned q = (unsigned)(ii - 1);
+            const int s = (int)(q / (64 * RL)), k = (int)((q % (64 * RL)) / RL), r = (int)(q % RL);
+            const int t = jj - 1 + k;
+            const int w = t / WIN;
+            if (s == cur_s && w == cur_w) code = win[cb * WB + ((t - w * WIN) * 64 + k) * RL + r];
         }
-        ++cnt;
+        const unsigned long long dm = __ballot(code == TB_DIAG);
+        const int L = (~dm == 0ull) ? 64 : __builtin_ctzll(~dm);        // leading run of diagonal moves
+        if (lane < L) ops[cnt + lane] = 'M';                             // hw2.cpp:164-169 / 240-245
+        cnt += L;
+        i -= L;
+        j -= L;
+        if (L < 64) {
+            const int c2 = __builtin_amdgcn_readlane(code, L);
+            if (c2 == TB_UP) {                                           // hw2.cpp:170-174 / 246-250
+                if (lane == 0) ops[cnt] = 'D';
+                ++cnt;
+                --i;
+            } else if (c2 == TB_LEFT) {                                  // hw2.cpp:175-179 / 251-255
+                if (lane == 0) ops[cnt] = 'I';
+                ++cnt;
+                --j;
+            } else if (LOCAL && c2 == TB_STOP) {                         // dp == 0, hw2.cpp:239
+                stopped = true;
+                break;
+            }
+            // 0xff: the cell lies in another window (or outside the matrix): next trip
+        }
     }
+    if (!LOCAL) {
+        // hw2.cpp:170-179 with j == 0 or i == 0: column 0 is all 'u', row 0 all 'l' (125-136)
+        for (int o = lane; o < i; o += 64) ops[cnt + o] = 'D';
+        cnt += i;
+        i = 0;
+        for (int o = lane; o < j; o += 64) ops[cnt + o] = 'I';
+        cnt += j;
+        j = 0;
+    }
+    (void)stopped;
     if (lane == 0) {
         res->start_i = (uint32_t)i;
         res->start_j = (uint32_t)j;
         res->n_ops = cnt;
-        res->overflow = overflow;
+        res->overflow = cnt > P.ops_cap ? 1u : 0u;   // cannot happen: a walk has at most n + m ops
     }
 }
 

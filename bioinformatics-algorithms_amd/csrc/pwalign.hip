@@ -722,7 +722,7 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
             return fail(ctx, PWA_E_NOMEM, "traceback band of a single pair exceeds free HBM");
         DevBuf d_band, d_ops, d_res;
         PairLaunch pl;
-        HIPC(ctx, d_band.alloc(band));
+        HIPC(ctx, d_band.alloc(band + 32768));   // + one traceback window: the walk stages whole windows
         HIPC(ctx, d_ops.alloc(opsb));
         HIPC(ctx, d_res.alloc(nc * sizeof(PairResult)));
         std::vector<PairResult> res(nc);
