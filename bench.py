@@ -32,11 +32,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.join(ROOT, "bioinformatics-algorithms_amd")
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s (= 157.3 TFLOP/s fp32 / 2)
-# VALU instructions per DP cell in the unrolled column block of each instantiation (counted in the
-# gfx950 ISA, see DESIGN.md "ops per cell"; tools/valu_per_cell.py re-derives them from the .so)
-VALU_PER_CELL = {"BM_SW,SC_PERM": 4.9, "BM_SW,SC_CMP": 6.9, "BM_NW,SC_PERM": 4.5, "BM_NW,SC_CMP": 6.5,
-                 "BM_NWG,SC_PERM": 2.5, "BM_NWG,SC_CMP": 4.5}
+# int32 VALU issue peak: one wave64 VALU instruction per 4 cycles per SIMD = 16 lanes/clk/SIMD.
+#   256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s  (SURVEY.md 8(d) uses the same figure).
+# Measured, not assumed: the C3 kernel retires 0.248 VALU instr/cycle/SIMD at 1, 2 and 4 waves per SIMD
+# (profiles/r01_c3_rocprof_summary.md: SQ_INSTS_VALU / GRBM_GUI_ACTIVE), and tools/valu_rate.hip shows
+# 4.1-4.6 cycles per wave64 v_max3_i32 / v_perm_b32 / v_add_u32_sdwa (and v_fma_f32) instruction.
+VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+# VALU instructions per evaluated DP cell of each instantiation: SQ_INSTS_VALU x 64 / padded cells from the
+# rocprofv3 PMC pass (c3: 5.02, c4: 2.53; profiles/), the others counted in the gfx950 ISA of the column block
+VALU_PER_CELL = {"BM_SW,SC_PERM": 5.02, "BM_SW,SC_CMP": 6.9, "BM_NW,SC_PERM": 4.5, "BM_NW,SC_CMP": 6.5,
+                 "BM_NWG,SC_PERM": 2.53, "BM_NWG,SC_CMP": 4.5}
 
 
 def load_pkg():
@@ -147,13 +152,14 @@ def build_c4(rank, world, n_seq=1024, slen=1000):
     seqs = [gen(1, 2, i, slen) for i in range(n_seq)]
     ii, jj = np.triu_indices(n_seq, k=1)
     n_pairs = len(ii)
-    per = (n_pairs + world - 1) // world
-    lo, hi = rank * per, min(n_pairs, (rank + 1) * per)
+    load_pkg()
+    from bioinformatics_algorithms_amd import shard
+    lo, hi, per = shard.block(n_pairs, world, rank)   # contiguous equal-count blocks, last one padded
     pa = ii[lo:hi].astype(np.uint32)
     pb = jj[lo:hi].astype(np.uint32)
     desc = {"workload": "c4: all-pairs NW scores, %d seq x %d bp (%d pairs) sharded over %d GPU(s), 1/-1/-1"
                         % (n_seq, slen, n_pairs, world),
-            "pairs_total": int(n_pairs), "scoring": [1, -1, -1]}
+            "pairs_total": int(n_pairs), "scoring": [1, -1, -1], "_per": int(per)}
     return "nw", seqs, pa, pb, (1, -1, -1), desc
 
 
@@ -201,28 +207,26 @@ def main():
     n_pairs = len(pa)
 
     stream = None
-    gathered = None
     mine = None
+    shard = None
+    state = {"gathered": None}
     if world > 1:
+        from bioinformatics_algorithms_amd import shard
         stream = torch.cuda.current_stream().cuda_stream
-        mine = torch.as_tensor(DevPtr(batch.d_scores(), n_pairs), device="cuda")
-        per = n_pairs
-        if args.workload == "c4":   # equal-count blocks, last one padded
-            per = (desc["pairs_total"] + world - 1) // world
-            if n_pairs < per:
-                pad = torch.zeros(per, dtype=torch.int32, device="cuda")
-                mine_src = mine
-                mine = pad
-                mine[:n_pairs].copy_(mine_src)   # refreshed every step below
-                desc["_padded"] = True
-        gathered = torch.empty(world * per, dtype=torch.int32, device="cuda")
+        mine = torch.empty(max(n_pairs, 1), dtype=torch.int32, device="cuda")[:n_pairs]
+        batch.set_d_scores(mine.data_ptr())   # kernels write the scores straight into the tensor the collective sends
+    n_total = desc.get("pairs_total", n_pairs * world)
+    per = desc.get("_per", n_pairs)
 
     def step():
         batch.run(stream)
-        if world > 1:
-            if desc.get("_padded"):
-                mine[:n_pairs].copy_(torch.as_tensor(DevPtr(batch.d_scores(), n_pairs), device="cuda"))
-            dist.all_gather_into_tensor(gathered, mine)   # RCCL over xGMI: per-pair int32 scores
+        if world > 1:   # RCCL all-gather of the per-pair int32 scores over xGMI (the path's only collective)
+            if args.workload == "c4":
+                state["gathered"] = shard.all_gather_scores(mine, n_total, per, dist)
+            else:       # weak scaling: every rank contributes n_pairs scores of its own texts
+                if state["gathered"] is None:
+                    state["gathered"] = torch.empty(world * n_pairs, dtype=torch.int32, device="cuda")
+                dist.all_gather_into_tensor(state["gathered"], mine)
 
     def sync():
         if world > 1:
@@ -269,7 +273,9 @@ def main():
     alg_bytes = sum(len(s) for s in seqs) + 4 * n_pairs            # inputs once + 4 B per pair
     kernel_gcups = cells / (k_ms * 1e-3) / 1e9
     roofline = {
-        "bound": "valu",   # int32 VALU issue: scores-only SW moves ~5e-6 B/cell over HBM
+        # int32 VALU issue bound: the scores-only pass moves ~5e-6 B/cell over HBM, so the
+        # contract's "hbm" / "mfma" bounds do not describe it; the HBM view is kept beside it under "hbm"
+        "bound": "valu",
         "kernel": kern,
         "achieved": (padded / (k_ms * 1e-3)) * ops / 1e12 if ops else None,
         "peak": VALU_PEAK_TOPS,
@@ -313,6 +319,19 @@ def main():
         line["verified_vs_cpu"] = {"pairs": len(ref_scores), "bit_exact": bool(ok)}
         if not ok:
             line["invalid"] = "GPU scores differ from the CPU baseline"
+    if world == 1:
+        # whole host call on HOST buffers (never `value`): sequence upload over PCIe, host-side wave-task
+        # scheduling, kernel, score download
+        t1 = time.perf_counter()
+        again = ctx.scores(mode, seqs, pa[:n_pairs], pb[:n_pairs], *scoring) if n_pairs <= 200000 else None
+        if again is None:
+            b2 = ctx.batch(mode, seqs, pa, pb, *scoring)
+            b2.run()
+            again = b2.fetch(numpy_out=True)
+            b2.close()
+        dt = time.perf_counter() - t1
+        line["host_call_inclusive"] = {"gcups": cells / dt / 1e9, "ms": dt * 1e3,
+                                       "what": "pwa_batch_create (PCIe upload + host scheduling) + run + fetch"}
     line["checksum"] = int(np.asarray(scores, dtype=np.int64).sum())
     print(json.dumps(line), flush=True)
     if dist is not None:

@@ -24,7 +24,7 @@ MODE = {"nw": 0, "sw": 1, "global": 0, "local": 1}
 
 EXPORTS = [
     "pwa_version", "pwa_strerror", "pwa_ctx_create", "pwa_ctx_destroy", "pwa_last_error", "pwa_scores",
-    "pwa_batch_create", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_fetch", "pwa_batch_info",
+    "pwa_batch_create", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_set_d_scores", "pwa_batch_fetch", "pwa_batch_info",
     "pwa_batch_last_ms", "pwa_batch_run_times", "pwa_batch_destroy", "pwa_align", "pwa_align_last_stats", "pwa_align_batch",
     "pwa_cigar_bound", "pwa_mdz_bound", "pwa_format_alignment",
 ]
@@ -61,6 +61,7 @@ def lib():
     L.pwa_batch_run.argtypes = [vp, vp]
     L.pwa_batch_d_scores.argtypes = [vp]
     L.pwa_batch_d_scores.restype = vp
+    L.pwa_batch_set_d_scores.argtypes = [vp, vp]
     L.pwa_batch_fetch.argtypes = [vp, i32p, u32p, u32p]
     L.pwa_batch_info.argtypes = [vp, u64p, u64p, u64p, C.POINTER(C.c_char_p)]
     L.pwa_batch_last_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -237,6 +238,10 @@ class Batch:
 
     def d_scores(self):
         return self._L.pwa_batch_d_scores(self._h)
+
+    def set_d_scores(self, device_ptr):
+        """Redirect the score vector to caller-owned device memory (e.g. tensor.data_ptr())."""
+        self._ctx._check(self._L.pwa_batch_set_d_scores(self._h, device_ptr), "pwa_batch_set_d_scores")
 
     def last_ms(self):
         ms = C.c_float(0)

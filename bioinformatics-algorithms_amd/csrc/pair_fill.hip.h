@@ -61,6 +61,8 @@ struct PairDesc {          // one pair of a launch
     uint32_t first_task;  // index of this pair's stripe 0 in the task list
     uint32_t n_stripes;
     uint32_t row_stride;  // >= m + 64
+    uint32_t out_index;   // slot of this pair in PairParams::scores_out
+    uint32_t pad;
 };
 
 struct StripeTask {
@@ -74,6 +76,7 @@ struct PairParams {
     uint32_t* queue;        // [0] atomic task counter, [1] error flag (both zeroed before every launch)
     uint32_t* progress;     // per task: number of finished 64-step chunks (zeroed before every launch)
     StripeBest* best;       // per task (SW)
+    int32_t* scores_out;    // optional device score vector in caller order (nullptr: results only in PairResult)
     int32_t match, mismatch, gap;
 };
 
@@ -337,9 +340,11 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
             }
         }
         if (lane == 0) res->score = sb;
+        if (lane == 0 && G.scores_out) ((g_i32*)G.scores_out)[P.out_index] = sb;
     } else {
         i = P.n;
         j = P.m;
+        if (lane == 0 && G.scores_out) ((g_i32*)G.scores_out)[P.out_index] = res->score;   // written by the fill (hw2.cpp:186)
     }
     i = __builtin_amdgcn_readfirstlane(i);
     j = __builtin_amdgcn_readfirstlane(j);

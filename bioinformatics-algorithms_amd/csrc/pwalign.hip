@@ -211,6 +211,7 @@ struct pwa_batch {
     std::vector<int32_t> host_scores;   // trivial pairs resolved on the host
     std::vector<uint32_t> host_end_i, host_end_j;
     std::string kernel_name;
+    int32_t* ext_scores = nullptr;      // caller-owned device score vector (pwa_batch_set_d_scores)
     static constexpr int kRing = 64;          // event pairs of the most recent runs
     hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
     uint64_t n_runs = 0;
@@ -532,12 +533,14 @@ int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, c
             pd[q].n = (int32_t)slen(pair_a[k]);
             pd[q].m = (int32_t)slen(pair_b[k]);
             pd[q].res = b->pair_res.as<PairResult>() + q;
+            pd[q].out_index = k;
             const uint64_t n = slen(pair_a[k]), m = slen(pair_b[k]);
             b->padded_cells += (n + 64 * kRL - 1) / (64 * kRL) * (64 * kRL) * m;
         }
         {
             const int rc = b->pl.build(ctx, pd, match, mismatch, gap);
             if (rc != PWA_OK) return rc;
+            b->pl.G.scores_out = b->scores.as<int32_t>();   // the device score vector is complete after run()
         }
         b->kernel_name = local ? "pair_fill_kernel<RL=4,SW,no-traceback>" : "pair_fill_kernel<RL=4,NW,no-traceback>";
     }
@@ -568,7 +571,22 @@ int pwa_batch_run(pwa_batch* b, void* stream_v) {
     return PWA_OK;
 }
 
-int32_t* pwa_batch_d_scores(pwa_batch* b) { return b ? b->scores.as<int32_t>() : nullptr; }
+int32_t* pwa_batch_d_scores(pwa_batch* b) {
+    if (!b) return nullptr;
+    return b->ext_scores ? b->ext_scores : b->scores.as<int32_t>();
+}
+
+int pwa_batch_set_d_scores(pwa_batch* b, int32_t* d_scores) {
+    if (!b || !d_scores) return PWA_E_INVALID;
+    pwa_ctx* ctx = b->ctx;
+    HIPC(ctx, hipSetDevice(ctx->device));
+    // carry over what is already there (pairs with an empty side are resolved at create time)
+    HIPC(ctx, hipMemcpy(d_scores, pwa_batch_d_scores(b), b->n_pairs * sizeof(int32_t), hipMemcpyDeviceToDevice));
+    b->ext_scores = d_scores;
+    b->bp.scores = d_scores;
+    b->pl.G.scores_out = d_scores;
+    return PWA_OK;
+}
 
 int pwa_batch_last_ms(pwa_batch* b, float* ms) {
     if (!b || !ms || !b->ran) return PWA_E_INVALID;
@@ -608,7 +626,7 @@ int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint3
     if (!b->ran) return fail(ctx, PWA_E_INVALID, "pwa_batch_run has not been called");
     HIPC(ctx, hipEventSynchronize(b->ev1[(b->n_runs - 1) % pwa_batch::kRing]));
     if (b->use_strips || b->n_live == 0) {
-        HIPC(ctx, hipMemcpy(score_out, b->scores.p, b->n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPC(ctx, hipMemcpy(score_out, pwa_batch_d_scores(b), b->n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost));
         if (b->want_end) {   // only reachable with no live pairs
             if (end_i_out) std::memcpy(end_i_out, b->host_end_i.data(), b->n_pairs * 4);
             if (end_j_out) std::memcpy(end_j_out, b->host_end_j.data(), b->n_pairs * 4);
@@ -632,8 +650,6 @@ int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint3
         if (end_i_out) end_i_out[k] = res[q].end_i;
         if (end_j_out) end_j_out[k] = res[q].end_j;
     }
-    // keep the device-side score vector coherent with what was fetched
-    HIPC(ctx, hipMemcpy(b->scores.p, score_out, b->n_pairs * sizeof(int32_t), hipMemcpyHostToDevice));
     return PWA_OK;
 }
 

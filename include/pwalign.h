@@ -74,7 +74,8 @@ int pwa_scores(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const u
  *   pwa_batch_create  uploads the sequences, builds the wave-task list (host), allocates outputs;
  *   pwa_batch_run     enqueues the kernels on `stream` (a hipStream_t, NULL = the context's own
  *                     stream) -- asynchronous, no host synchronisation, graph-capturable;
- *   pwa_batch_d_scores  device pointer to int32[n_pairs] in pair order (valid until destroy);
+ *   pwa_batch_d_scores  device pointer to int32[n_pairs] in pair order (valid until destroy),
+ *                     complete once the run has finished on its stream;
  *   pwa_batch_fetch   synchronises the stream and copies scores (and end cells, if requested at
  *                     create time) to host buffers.
  */
@@ -83,6 +84,9 @@ int pwa_batch_create(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, c
                      uint64_t n_pairs, int want_end_cells, pwa_batch **out);
 int pwa_batch_run(pwa_batch *b, void *stream);
 int32_t *pwa_batch_d_scores(pwa_batch *b);
+/* Redirect the score vector to caller-owned DEVICE memory (int32[n_pairs], e.g. a torch tensor's
+ * data_ptr) so that it can be handed to a collective without aliasing library memory. */
+int pwa_batch_set_d_scores(pwa_batch *b, int32_t *d_scores);
 int pwa_batch_fetch(pwa_batch *b, int32_t *score_out, uint32_t *end_i_out, uint32_t *end_j_out);
 /* Facts about the prepared batch for reporting: cells = sum n*m; padded_cells = cells the kernels
  * actually evaluate (register-tile padding); kernel_name = the dominant kernel instantiation. */

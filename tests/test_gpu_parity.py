@@ -263,3 +263,22 @@ def test_cli_many_pairs_against_oracle_cli(pkg, tmp_path):
             rc2, _ = O.run_cli(O.ORACLE_CLI, args + ["-o", b], cwd=tmp_path)
             assert rc1 == rc2 == 0
             assert a.read_bytes() == b.read_bytes()
+
+
+def test_device_score_vector_in_caller_memory(ctx):
+    """pwa_batch_set_d_scores: kernels write into a torch tensor (what bench.py hands to the RCCL all-gather);
+    both engines, including pairs with an empty side."""
+    import torch
+    seqs = [O.gen(5, 0, i, 100 + i) for i in range(40)] + [b"", O.gen(5, 1, 0, 500)]
+    pa = list(range(41))
+    pb = [41] * 41
+    for mode, sc in (("sw", (1, -1, -1)), ("nw", (1, -1, -1)), ("sw", (1, 1, 1))):   # (1,1,1) -> pair engine
+        b = ctx.batch(mode, seqs, pa, pb, *sc)
+        t = torch.full((len(pa),), -12345, dtype=torch.int32, device="cuda")
+        b.set_d_scores(t.data_ptr())
+        b.run()
+        b.last_ms()
+        want = [O.score(mode, seqs[a], seqs[bb], *sc)[0] for a, bb in zip(pa, pb)]
+        assert t.cpu().tolist() == want, (mode, sc)
+        assert b.fetch() == want
+        b.close()
