@@ -212,7 +212,12 @@ def main():
     state = {"gathered": None}
     if world > 1:
         from bioinformatics_algorithms_amd import shard
-        stream = torch.cuda.current_stream().cuda_stream
+        # a real (non-default) torch stream: the kernels are enqueued on it through the C ABI and the
+        # collective, issued under the same current stream, is ordered behind them
+        tstream = torch.cuda.Stream()
+        torch.cuda.set_stream(tstream)
+        stream = tstream.cuda_stream
+        assert stream != 0
         mine = torch.empty(max(n_pairs, 1), dtype=torch.int32, device="cuda")[:n_pairs]
         batch.set_d_scores(mine.data_ptr())   # kernels write the scores straight into the tensor the collective sends
     n_total = desc.get("pairs_total", n_pairs * world)
