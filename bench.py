@@ -181,7 +181,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     torch = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1 takes the distributed code path (RCCL init, explicit stream, all-gather) even with
+    # one rank: rehearsal on a 1-GPU box under `python -m torch.distributed.run --nproc-per-node 1 ...`
+    use_dist = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))
+    if use_dist:
         import torch   # noqa: F811
         import torch.distributed as dist   # noqa: F811
         torch.cuda.set_device(local_rank)
@@ -191,7 +194,7 @@ def main():
     ctx = pkg.Context(local_rank)
 
     if args.workload in ("c2", "c5"):
-        return bench_single_pair(args, pkg, ctx, rank, world, dist, torch)
+        return bench_single_pair(args, pkg, ctx, rank, world, dist if use_dist else None, torch)
 
     if args.workload == "c3":
         kw = dict(n_patterns=256, n_texts=16, tlen=2000) if args.small else {}
@@ -210,7 +213,7 @@ def main():
     mine = None
     shard = None
     state = {"gathered": None}
-    if world > 1:
+    if use_dist:
         from bioinformatics_algorithms_amd import shard
         # a real (non-default) torch stream: the kernels are enqueued on it through the C ABI and the
         # collective, issued under the same current stream, is ordered behind them
@@ -225,7 +228,7 @@ def main():
 
     def step():
         batch.run(stream)
-        if world > 1:   # RCCL all-gather of the per-pair int32 scores over xGMI (the path's only collective)
+        if use_dist:   # RCCL all-gather of the per-pair int32 scores over xGMI (the path's only collective)
             if args.workload == "c4":
                 state["gathered"] = shard.all_gather_scores(mine, n_total, per, dist)
             else:       # weak scaling: every rank contributes n_pairs scores of its own texts
@@ -234,7 +237,7 @@ def main():
                 dist.all_gather_into_tensor(state["gathered"], mine)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
         else:
@@ -252,7 +255,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = batch.run_times(min(args.steps, 64))   # HIP events on the launch stream, per step
     cells = info["cells"]
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

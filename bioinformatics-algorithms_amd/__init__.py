@@ -25,7 +25,7 @@ MODE = {"nw": 0, "sw": 1, "global": 0, "local": 1}
 EXPORTS = [
     "pwa_version", "pwa_strerror", "pwa_ctx_create", "pwa_ctx_destroy", "pwa_last_error", "pwa_scores",
     "pwa_batch_create", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_set_d_scores", "pwa_batch_fetch", "pwa_batch_info",
-    "pwa_batch_last_ms", "pwa_batch_run_times", "pwa_batch_destroy", "pwa_align", "pwa_align_last_stats", "pwa_align_batch",
+    "pwa_batch_last_ms", "pwa_batch_run_times", "pwa_batch_destroy", "pwa_align", "pwa_align_matrices", "pwa_align_last_stats", "pwa_align_batch",
     "pwa_cigar_bound", "pwa_mdz_bound", "pwa_format_alignment",
 ]
 
@@ -70,6 +70,7 @@ def lib():
     L.pwa_batch_destroy.restype = None
     L.pwa_align.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_uint64, vp, C.c_uint64, i32p, vp,
                             C.c_uint64, u64p, u64p, u64p]
+    L.pwa_align_matrices.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_uint64, vp, C.c_uint64, vp, vp]
     L.pwa_align_last_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), u64p]
     L.pwa_align_batch.argtypes = batch_in + [i32p, vp, u64p, u64p, u64p, u64p]
     L.pwa_cigar_bound.argtypes = [C.c_uint64]
@@ -179,6 +180,18 @@ class Context:
         if not raw:
             out.update(format_alignment(pattern, text, out["ops"], out["end"]))
         return out
+
+    def matrices(self, mode, pattern, text, match, mismatch, gap):
+        """(dp, traceback) as numpy arrays (n+1, m+1): the reference's two per-pair matrices (hw2.cpp:119-120)."""
+        import numpy as np
+        pattern, text = _b(pattern), _b(text)
+        n, m = len(pattern), len(text)
+        dp = np.zeros((n + 1, m + 1), dtype=np.int32)
+        tb = np.zeros((n + 1, m + 1), dtype=np.uint8)
+        rc = self._L.pwa_align_matrices(self._h, MODE[mode], match, mismatch, gap, pattern, n, text, m,
+                                        dp.ctypes.data_as(C.c_void_p), tb.ctypes.data_as(C.c_void_p))
+        self._check(rc, "pwa_align_matrices")
+        return dp, tb
 
     def align_batch(self, mode, seqs, pair_a, pair_b, match, mismatch, gap):
         blob, off, seqs = pack_sequences(seqs)

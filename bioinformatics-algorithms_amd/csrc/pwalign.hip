@@ -169,10 +169,10 @@ struct PairLaunch {
         return PWA_OK;
     }
     // enqueue: zero the queue / progress words, fill, then the walk (or only the end-cell pick)
-    int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, bool walk, hipEvent_t after_fill) {
+    int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, bool walk, hipEvent_t after_fill, bool sband = false) {
         HIPC(ctx, hipMemsetAsync(queue.p, 0, 16, st));
         HIPC(ctx, hipMemsetAsync(progress.p, 0, progress.bytes, st));
-        hipLaunchKernelGGL(pair_fill_fn(local, tb, false), dim3(grid), dim3(64), 0, st, G);
+        hipLaunchKernelGGL(pair_fill_fn(local, tb, sband), dim3(grid), dim3(64), 0, st, G);
         HIPC(ctx, hipGetLastError());
         if (after_fill) HIPC(ctx, hipEventRecord(after_fill, st));
         hipLaunchKernelGGL(pair_tb_fn(local, walk), dim3(G.n_pairs), dim3(64), 0, st, G);   // one wave per pair
@@ -836,6 +836,69 @@ int pwa_align(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const ui
     const uint64_t ooff = 0;
     return pwa_align_batch(ctx, mode, match, mismatch, gap, bytes.data(), off, 2, &a, &b, 1, score, ops, &ooff, n_ops,
                            end_cell, start_cell);
+}
+
+int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* pattern, uint64_t n,
+                       const uint8_t* text, uint64_t m, int32_t* dp_out, char* tb_out) {
+    if (!ctx) return PWA_E_INVALID;
+    if (mode != PWA_MODE_NW && mode != PWA_MODE_SW) return fail(ctx, PWA_E_INVALID, "unknown mode");
+    if ((n && !pattern) || (m && !text) || (!dp_out && !tb_out)) return fail(ctx, PWA_E_INVALID, "null input");
+    if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
+    const bool local = mode == PWA_MODE_SW;
+    const uint64_t W = m + 1;
+    // row 0 and column 0 exactly as the reference initialises them (hw2.cpp:119-136 / 193-194)
+    for (uint64_t i = 0; i <= n; ++i) {
+        if (dp_out) dp_out[i * W] = local ? 0 : wrap_mul((int64_t)i, gap);
+        if (tb_out) tb_out[i * W] = (!local && i > 0) ? 'u' : ' ';
+    }
+    for (uint64_t j = 0; j <= m; ++j) {
+        if (dp_out) dp_out[j] = local ? 0 : wrap_mul((int64_t)j, gap);
+        if (tb_out) tb_out[j] = (!local && j > 0) ? 'l' : ' ';
+    }
+    if (n == 0 || m == 0) return PWA_OK;
+    HIPC(ctx, hipSetDevice(ctx->device));
+    const uint64_t band = tb_band_bytes(n, m);
+    DevBuf d_pat, d_txt, d_band, d_sband, d_res;
+    HIPC(ctx, d_pat.alloc(n + 64));
+    HIPC(ctx, d_txt.alloc(m + 64));
+    HIPC(ctx, d_band.alloc(band + 32768));
+    HIPC(ctx, d_sband.alloc(band * sizeof(int32_t)));
+    HIPC(ctx, d_res.alloc(sizeof(PairResult)));
+    HIPC(ctx, hipMemcpy(d_pat.p, pattern, n, hipMemcpyHostToDevice));
+    HIPC(ctx, hipMemcpy(d_txt.p, text, m, hipMemcpyHostToDevice));
+    HIPC(ctx, hipMemset(d_res.p, 0, sizeof(PairResult)));
+    std::vector<PairDesc> pd(1);
+    std::memset(&pd[0], 0, sizeof(PairDesc));
+    pd[0].pat = d_pat.as<uint8_t>();
+    pd[0].txt = d_txt.as<uint8_t>();
+    pd[0].n = (int32_t)n;
+    pd[0].m = (int32_t)m;
+    pd[0].tb = d_band.as<uint8_t>();
+    pd[0].sband = d_sband.as<int32_t>();
+    pd[0].res = d_res.as<PairResult>();
+    PairLaunch pl;
+    int rc = pl.build(ctx, pd, match, mismatch, gap);
+    if (rc != PWA_OK) return rc;
+    rc = pl.launch(ctx, ctx->stream, local, true, false, nullptr, true);
+    if (rc != PWA_OK) return rc;
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    rc = pl.check(ctx);
+    if (rc != PWA_OK) return rc;
+    std::vector<uint8_t> hb(tb_out ? band : 0);
+    std::vector<int32_t> hs(dp_out ? band : 0);
+    if (tb_out) HIPC(ctx, hipMemcpy(hb.data(), d_band.p, band, hipMemcpyDeviceToHost));
+    if (dp_out) HIPC(ctx, hipMemcpy(hs.data(), d_sband.p, band * sizeof(int32_t), hipMemcpyDeviceToHost));
+    static const char kCode[4] = {'0', 'd', 'u', 'l'};   // hw2.cpp:214-222 / 145-153
+    const uint64_t T = m + 63;
+    for (uint64_t i = 1; i <= n; ++i) {
+        const uint64_t q = i - 1, st = q / (64 * kRL), k = (q % (64 * kRL)) / kRL, r = q % kRL;
+        for (uint64_t j = 1; j <= m; ++j) {
+            const uint64_t idx = ((st * T + (j - 1 + k)) * 64 + k) * kRL + r;   // skewed band -> row-major matrix
+            if (tb_out) tb_out[i * W + j] = kCode[hb[idx] & 3];
+            if (dp_out) dp_out[i * W + j] = hs[idx];
+        }
+    }
+    return PWA_OK;
 }
 
 int pwa_align_last_stats(const pwa_ctx* ctx, float* fill_ms, float* traceback_ms, uint64_t* band_bytes) {

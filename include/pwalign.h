@@ -116,6 +116,17 @@ int pwa_align(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const ui
               const uint8_t *text, uint64_t m, int32_t *score, uint8_t *ops, uint64_t ops_cap, uint64_t *n_ops,
               uint64_t end_cell[2], uint64_t start_cell[2]);
 
+/*
+ * The two matrices the reference keeps per pair, in the reference's own row-major form (for
+ * inspection and whole-matrix parity tests; sizes are the caller's problem: 5 B per cell):
+ *   dp_out : int32 (n+1) x (m+1) = `dp`        (hw2.cpp:119 / 193), or NULL
+ *   tb_out : char  (n+1) x (m+1) = `traceback` (hw2.cpp:120 / 194): ' ', 'd', 'u', 'l', '0', or NULL
+ * On the device both are written as skewed bands (int32 score band + 1 B/cell traceback band, one
+ * coalesced wave store per anti-diagonal step); the host un-skews them.
+ */
+int pwa_align_matrices(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const uint8_t *pattern, uint64_t n,
+                       const uint8_t *text, uint64_t m, int32_t *dp_out, char *tb_out);
+
 /* Device time in ms of the fill kernel(s) / traceback kernel of the last pwa_align on ctx, and
  * the bytes of traceback band it wrote to HBM (for roofline accounting). */
 int pwa_align_last_stats(const pwa_ctx *ctx, float *fill_ms, float *traceback_ms, uint64_t *band_bytes);

@@ -305,6 +305,44 @@ orc_result *orc_sw(const char *p, size_t n, const char *t, size_t m, int match, 
     return finish_result(best, &ap, &ar, &ops, end_i, end_j, ti, tj);
 }
 
+/* ------------------------------------------------ the matrices themselves */
+void orc_matrices(int mode, const char *p, size_t n, const char *t, size_t m, int match, int mismatch, int gap,
+                  int32_t *dp, char *tb) {
+    const size_t W = m + 1;
+    memset(dp, 0, (n + 1) * W * sizeof(int32_t));                    /* 119 / 193 */
+    memset(tb, ' ', (n + 1) * W);                                    /* 120 / 194 */
+    if (mode == 0) {
+        for (size_t i = 0; i <= n; ++i) {                            /* 125-130 */
+            dp[i * W] = wrap_mul_idx(i, gap);
+            if (i > 0) tb[i * W] = 'u';
+        }
+        for (size_t j = 0; j <= m; ++j) {                            /* 131-136 */
+            dp[j] = wrap_mul_idx(j, gap);
+            if (j > 0) tb[j] = 'l';
+        }
+    }
+    for (size_t i = 1; i <= n; ++i)
+        for (size_t j = 1; j <= m; ++j) {
+            int32_t dg = wrap_add(dp[(i - 1) * W + j - 1], p[i - 1] == t[j - 1] ? match : mismatch);
+            int32_t up = wrap_add(dp[(i - 1) * W + j], gap), left = wrap_add(dp[i * W + j - 1], gap);
+            int32_t v;
+            char c;
+            if (mode == 0) {                                         /* 142-153 */
+                v = dg;
+                c = 'd';
+                if (left > v) { v = left; c = 'l'; }
+                if (up > v) { v = up; c = 'u'; }
+            } else {                                                 /* 211-222 */
+                v = up > left ? up : left;
+                if (dg > v) v = dg;
+                if (v < 0) v = 0;
+                c = v == 0 ? '0' : v == dg ? 'd' : v == up ? 'u' : 'l';
+            }
+            dp[i * W + j] = v;
+            tb[i * W + j] = c;
+        }
+}
+
 /* ------------------------------------------------ compact forms (rolling rows + 1 B/cell codes) */
 orc_result *orc_nw_compact(const char *p, size_t n, const char *t, size_t m, int match, int mismatch, int gap) {
     const size_t W = m + 1;

@@ -43,6 +43,11 @@ orc_result *orc_nw(const char *p, size_t n, const char *t, size_t m, int match, 
 orc_result *orc_sw(const char *p, size_t n, const char *t, size_t m, int match, int mismatch, int gap);
 void orc_free(orc_result *r);
 
+/* The reference's two matrices themselves (hw2.cpp:119-156 / 193-231): dp int32 and traceback char,
+ * (n+1) x (m+1) row-major, written into caller buffers.  mode 0 = NW, 1 = SW. */
+void orc_matrices(int mode, const char *p, size_t n, const char *t, size_t m, int match, int mismatch, int gap,
+                  int32_t *dp, char *tb);
+
 /* Same results as orc_nw / orc_sw but with two rolling int rows + a 1 B/cell code
  * matrix (for sizes where 5 B/cell does not fit); differential-tested against the
  * full-matrix forms. */

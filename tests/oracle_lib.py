@@ -75,6 +75,8 @@ def oracle():
         lib.orc_cigar.restype = C.c_void_p
         lib.orc_mdz.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
         lib.orc_mdz.restype = C.c_void_p
+        lib.orc_matrices.argtypes = [C.c_int] + sig + [C.c_void_p, C.c_void_p]
+        lib.orc_matrices.restype = None
         lib.orc_gen.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t, C.c_char_p]
         lib.orc_gen.restype = None
         lib.orc_hw2_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
@@ -133,6 +135,17 @@ def align(mode, p, t, match, mismatch, gap, compact=False):
     out["overlap"] = lib.orc_overlap(out["aligned_pattern"], out["aligned_reference"], len(out["aligned_pattern"]))
     lib.orc_free(r)
     return out
+
+
+def matrices(mode, p, t, match, mismatch, gap):
+    """The reference's dp (int32) and traceback (char) matrices, (n+1, m+1) numpy arrays."""
+    import numpy as np
+    p, t = _as_bytes(p), _as_bytes(t)
+    dp = np.zeros((len(p) + 1, len(t) + 1), dtype=np.int32)
+    tb = np.zeros((len(p) + 1, len(t) + 1), dtype=np.uint8)
+    oracle().orc_matrices(0 if mode == "nw" else 1, p, len(p), t, len(t), match, mismatch, gap,
+                          dp.ctypes.data_as(C.c_void_p), tb.ctypes.data_as(C.c_void_p))
+    return dp, tb
 
 
 def score(mode, p, t, match, mismatch, gap):

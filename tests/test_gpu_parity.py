@@ -282,3 +282,20 @@ def test_device_score_vector_in_caller_memory(ctx):
         assert t.cpu().tolist() == want, (mode, sc)
         assert b.fetch() == want
         b.close()
+
+
+def test_whole_matrices_match_reference_matrices(ctx):
+    """Every cell of the int32 score band and of the traceback band == the reference's `dp` and `traceback`
+    matrices (hw2.cpp:119-156 / 193-231), incl. row/column 0, several stripes, all scorings."""
+    import numpy as np
+    rng = random.Random(42)
+    cases = [(1, 1), (3, 70), (70, 3), (255, 300), (256, 64), (257, 65), (600, 777), (1100, 90)]
+    for (n, m) in cases:
+        p = bytes(rng.choice(b"ACGT") for _ in range(n))
+        t = bytes(rng.choice(b"ACGT") for _ in range(m))
+        for sc in rng.sample(SCORINGS, 4):
+            for mode in ("nw", "sw"):
+                dp, tb = ctx.matrices(mode, p, t, *sc)
+                wdp, wtb = O.matrices(mode, p, t, *sc)
+                assert np.array_equal(dp, wdp), (mode, n, m, sc)
+                assert np.array_equal(tb, wtb), (mode, n, m, sc)

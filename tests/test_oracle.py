@@ -144,3 +144,29 @@ def test_oracle_differential_against_compiled_reference():
             a, b = O.align(mode, p, t, *sc), O.ref_align(mode, p, t, *sc)
             for k in ("score", "aligned_pattern", "aligned_reference", "cigar", "mdz", "overlap"):
                 assert a[k] == b[k], (mode, p, t, sc, k)
+
+
+def test_oracle_matrices_consistent_with_pinned_alignment():
+    """orc_matrices (used for whole-matrix GPU parity) must reproduce the pinned functions: dp[n][m] / max dp
+    = score, and walking its traceback matrix by the reference's rules gives the pinned op list."""
+    import numpy as np
+    rng = random.Random(9)
+    for it in range(60):
+        p = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 50)))
+        t = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 50)))
+        sc = rng.choice([(1, -1, -1), (2, -3, -5), (1, 1, 1), (0, 0, 0), (-1, 2, 1)])
+        for mode in ("nw", "sw"):
+            dp, tb = O.matrices(mode, p, t, *sc)
+            a = O.align(mode, p, t, *sc)
+            i, j = a["end"]
+            assert (dp[len(p), len(t)] if mode == "nw" else dp.max()) == a["score"]
+            ops = bytearray()
+            while (i > 0 or j > 0) if mode == "nw" else (i > 0 and j > 0 and dp[i, j] != 0):
+                c = chr(tb[i, j])
+                if c == "d":
+                    ops += b"M"; i -= 1; j -= 1
+                elif c == "u":
+                    ops += b"D"; i -= 1
+                else:
+                    ops += b"I"; j -= 1
+            assert bytes(ops) == a["ops"] and (i, j) == tuple(a["start"])
