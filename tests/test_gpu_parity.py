@@ -299,3 +299,45 @@ def test_whole_matrices_match_reference_matrices(ctx):
                 wdp, wtb = O.matrices(mode, p, t, *sc)
                 assert np.array_equal(dp, wdp), (mode, n, m, sc)
                 assert np.array_equal(tb, wtb), (mode, n, m, sc)
+
+
+def test_scores_degenerate_shapes(ctx):
+    """empty batch, texts shorter than one 4-column block, very long pattern against tiny texts,
+    duplicate pairs, a pattern aligned with itself."""
+    assert ctx.scores("sw", [b"ACGT"], [], [], 1, -1, -1) == []
+    long_p = O.gen(11, 0, 0, 5000)
+    seqs = [long_p, b"A", b"AC", b"ACG", b"ACGT", b"ACGTA", b"", O.gen(11, 1, 0, 301)]
+    pa = [0, 0, 0, 0, 0, 0, 0, 7, 7, 0, 1, 2, 3, 4, 5, 7, 7]
+    pb = [1, 2, 3, 4, 5, 6, 7, 7, 7, 0, 1, 1, 1, 1, 1, 1, 6]
+    for sc in [(1, -1, -1), (2, -3, -5), (1, 1, 1)]:
+        for mode in ("nw", "sw"):
+            got = ctx.scores(mode, seqs, pa, pb, *sc)
+            want = [O.score(mode, seqs[a], seqs[b], *sc)[0] for a, b in zip(pa, pb)]
+            assert got == want, (mode, sc, got, want)
+            s, ei, ej = ctx.scores(mode, seqs, pa, pb, *sc, want_end=True)
+            assert [(x, y, z) for x, y, z in zip(s, ei, ej)] == [tuple(O.score(mode, seqs[a], seqs[b], *sc)) for a, b in zip(pa, pb)]
+
+
+def test_align_degenerate_shapes(ctx):
+    for p, t in [(b"A", b"A"), (b"A", b"C"), (b"", b"ACGT"), (b"ACGT", b""), (b"", b""), (O.gen(2, 0, 0, 1300), b"ACG"),
+                 (b"ACG", O.gen(2, 1, 0, 1300)), (O.gen(2, 0, 1, 257), O.gen(2, 0, 1, 257))]:
+        for sc in [(1, -1, -1), (1, -3, -1), (1, 1, 1)]:
+            for mode in ("nw", "sw"):
+                got = ctx.align(mode, p, t, *sc)
+                want = O.align(mode, p, t, *sc)
+                check_alignment(got, want)
+                assert got["ops"] == want["ops"] and tuple(got["end"]) == tuple(want["end"])
+
+
+def test_error_reporting(ctx, pkg):
+    with pytest.raises(pkg.PwaError):
+        ctx.scores("sw", [b"ACGT"], [0], [5], 1, -1, -1)        # pair index out of range
+    import ctypes as C
+    L = pkg.lib()
+    score = C.c_int32()
+    n_ops = C.c_uint64()
+    ops = C.create_string_buffer(4)
+    rc = L.pwa_align(ctx._h, 1, 1, -1, -1, b"ACGTACGT", 8, b"ACGTACGT", 8, C.byref(score), ops, 4, C.byref(n_ops), None, None)
+    assert rc == -5 and b"ops_cap" in L.pwa_last_error(ctx._h)   # PWA_E_CAPACITY
+    rc = L.pwa_align(ctx._h, 7, 1, -1, -1, b"A", 1, b"A", 1, C.byref(score), ops, 4, C.byref(n_ops), None, None)
+    assert rc == -1
