@@ -187,6 +187,7 @@ def main():
     if use_dist:
         import torch   # noqa: F811
         import torch.distributed as dist   # noqa: F811
+        os.environ["NCCL_DEBUG"] = os.environ.get("BENCH_NCCL_DEBUG", "WARN")   # keep RCCL's banner off stdout: ONE JSON line
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 

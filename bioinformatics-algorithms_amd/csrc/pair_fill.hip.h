@@ -12,7 +12,9 @@
 //     the row above a lane's first row comes from lane k-1 one step earlier through a DPP
 //     wave-shift (no LDS), as does the text character, which enters at lane 0 and travels down;
 //   * the stripes of one pair run CONCURRENTLY on different CUs as a software pipeline: stripe s
-//     consumes the bottom row of stripe s-1 two 64-step chunks behind it.  The hand-off goes
+//     consumes the bottom row of stripe s-1 a few CH-step chunks behind it (the producer's lane 63 is
+//     63 steps behind its lane 0, publication is deferred by one chunk so that no store drain sits in
+//     the loop, and the consumer polls / loads one chunk ahead of use).  The hand-off goes
 //     through a per-stripe row buffer in HBM: write-through (sc1) stores, the storing wave's
 //     vmcnt(0) drain, one sc1 progress-counter store by one lane; the consumer polls that counter
 //     with sc1 loads and reads the row with sc1 loads (cdna_hip_programming.md Guideline 16, R1 /
@@ -169,6 +171,8 @@ __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i
     if (TB) {
         if (RL == 4) {
             ((g_u32*)tbs)[(size_t)t * 64 + lane] = codes;
+        } else if (RL == 2) {
+            ((PWA_GLOBAL uint16_t*)tbs)[(size_t)t * 64 + lane] = (uint16_t)codes;
         } else {
 #pragma unroll
             for (int r = 0; r < RL; ++r) tbs[((size_t)t * 64 + lane) * RL + r] = (uint8_t)(codes >> (8 * r));
@@ -180,8 +184,9 @@ __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i
     }
 }
 
-template <int RL, bool LOCAL, bool TB, bool SBAND>
+template <int RL, int CH, bool LOCAL, bool TB, bool SBAND>
 __global__ __launch_bounds__(64) void pair_fill_kernel(const PairParams G) {
+    static_assert(CH == 16 || CH == 32, "chunk length");
     const int lane = threadIdx.x;
     const int match = G.match, mismatch = G.mismatch, gap = G.gap;
     for (;;) {
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(64) void pair_fill_kernel(const PairParams G) {
         const int s = (int)task.stripe;
         const int n = P.n, m = P.m;
         const int T = m + 63;
-        const int n_chunks = (T + 63) >> 6;
+        const int n_chunks = (T + CH - 1) / CH;
         const bool has_top = s > 0;
         const bool has_bot = (uint32_t)(s + 1) < P.n_stripes;
 
@@ -220,54 +225,85 @@ __global__ __launch_bounds__(64) void pair_fill_kernel(const PairParams G) {
         g_i32* sbs = SBAND ? (g_i32*)(P.sband + (size_t)s * T * 64 * RL) : nullptr;
         g_cu8* txt = (g_cu8*)P.txt;
         PWA_GLOBAL PairResult* res = (PWA_GLOBAL PairResult*)P.res;
+        // progress word of a stripe = number of bottom-row COLUMNS that are visible to other CUs
         g_u32* prog_in = (g_u32*)(G.progress + (has_top ? tid - 1 : tid));   // previous stripe of the same pair
         g_u32* prog_out = (g_u32*)(G.progress + tid);
 
         int bottom = 0, tch = 0, coll = 0;
+        // consumer-side run-ahead: the producer's counter is polled one chunk early and, when it already
+        // covers the next chunk, that chunk's row is loaded one chunk early -- in steady state neither the
+        // poll's nor the row load's latency is on the critical path (it only lengthens the pipeline lag)
+        uint32_t pub_seen = 0;
+        int row_next = 0, txt_next = (lane < CH && lane < m) ? (int)txt[lane] : 0;
+        bool row_next_valid = false;
         for (int ch = 0; ch < n_chunks; ++ch) {
-            const int t0 = ch << 6;
-            // ---- stage the row above the stripe and the text for columns t0 .. t0+63
-            int topv = 0, tcv = 0;
-            {
-                const int c = t0 + lane;
-                if (has_top) {
-                    const uint32_t need = (uint32_t)min(ch + 2, n_chunks);
+            const int t0 = ch * CH;
+            // ---- the row above the stripe and the text for columns t0 .. t0+CH-1 (lanes 0 .. CH-1)
+            int topv = 0;
+            const int c0 = t0 + lane;
+            if (has_top) {
+                if (row_next_valid) {
+                    topv = row_next;
+                } else {
+                    const uint32_t need = (uint32_t)min(m, t0 + CH);
                     uint32_t spins = 0;
-                    while (__hip_atomic_load(prog_in, PWA_RLX_AGENT) < need) {
-                        __builtin_amdgcn_s_sleep(4);
+                    while ((pub_seen = __hip_atomic_load(prog_in, PWA_RLX_AGENT)) < need) {
+                        __builtin_amdgcn_s_sleep(2);
                         if (++spins > (1u << 24)) {   // bounded spin: flag the failure and go on with junk
                             if (lane == 0) __hip_atomic_store((g_u32*)(G.queue + 1), 1u, PWA_RLX_AGENT);
                             break;
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only: row loads stay below the poll
-                    if (c < m) topv = __hip_atomic_load(rin + c, PWA_RLX_AGENT);   // sc1 load
-                } else if (!LOCAL) {
-                    topv = p_mulw(c + 1, gap);   // dp[0][j], hw2.cpp:131-136
+                    if (lane < CH && c0 < m) topv = __hip_atomic_load(rin + c0, PWA_RLX_AGENT);   // sc1 load
                 }
-                if (c < m) tcv = txt[c];
+            } else if (!LOCAL) {
+                topv = p_mulw(c0 + 1, gap);   // dp[0][j], hw2.cpp:131-136
             }
-            const bool interior = t0 >= 63 && t0 + 64 < m;   // every lane inside the matrix, last column not touched
+            int tcv = txt_next;
+            {   // ---- run-ahead for chunk ch+1
+                const int cn = t0 + CH + lane;
+                txt_next = (lane < CH && cn < m) ? (int)txt[cn] : 0;
+                row_next_valid = false;
+                if (has_top && ch + 1 < n_chunks) {
+                    const uint32_t need_n = (uint32_t)min(m, t0 + 2 * CH);
+                    if (pub_seen >= need_n) {   // known from a poll that completed before this load is issued
+                        row_next = (lane < CH && cn < m) ? __hip_atomic_load(rin + cn, PWA_RLX_AGENT) : 0;
+                        row_next_valid = true;
+                    }
+                    pub_seen = __hip_atomic_load(prog_in, PWA_RLX_AGENT);   // consumed one chunk later
+                }
+            }
+            const bool interior = t0 >= 63 && t0 + CH < m;   // every lane inside the matrix, last column not touched
             if (interior) {
 #pragma unroll 4
-                for (int q = 0; q < 64; ++q)
+                for (int q = 0; q < CH; ++q)
                     stripe_step<RL, LOCAL, TB, SBAND, false>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
                                                              tcv, coll, bs, bj, match, mismatch, gap, tbs, sbs, res);
             } else {
-                const int qn = min(64, T - t0);
+                const int qn = min(CH, T - t0);
 #pragma unroll 1
                 for (int q = 0; q < qn; ++q)
                     stripe_step<RL, LOCAL, TB, SBAND, true>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
                                                             tcv, coll, bs, bj, match, mismatch, gap, tbs, sbs, res);
 #pragma unroll 1
-                for (int q = qn; q < 64; ++q) coll = wave_shl1(bottom, coll);   // keep the collector aligned
+                for (int q = qn; q < CH; ++q) coll = wave_shl1(bottom, coll);   // keep the collector aligned
             }
-            // ---- publish the bottom row: after the chunk lane l holds column t0 - 63 + l
+            // ---- bottom row out: after the chunk lane 64-CH+q holds column t0 - 63 + q
             if (has_bot) {
-                const int c = t0 - 63 + lane;
-                if (c >= 0 && c < m) __hip_atomic_store(rout + c, coll, PWA_RLX_AGENT);   // sc1 (write-through) store
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // drain before the flag
-                if (lane == 0) __hip_atomic_store(prog_out, (uint32_t)(ch + 1), PWA_RLX_AGENT);
+                const int c = t0 - 63 + (lane - (64 - CH));
+                if (lane >= 64 - CH && c >= 0 && c < m) __hip_atomic_store(rout + c, coll, PWA_RLX_AGENT);   // sc1 (write-through)
+                if (ch + 1 < n_chunks) {
+                    // Deferred publication: do not drain this chunk's stores.  Once at most (TB ? CH : 0) + 1
+                    // younger operations are outstanding, the row store of the PREVIOUS chunk has completed
+                    // (vmcnt retires loads and stores in issue order), i.e. columns < t0 - 63 are visible.
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"((TB && !SBAND ? CH : 0) + 1) : "memory");
+                    const int pubv = min(m, t0 - 63);
+                    if (lane == 0 && pubv > 0) __hip_atomic_store(prog_out, (uint32_t)pubv, PWA_RLX_AGENT);
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(prog_out, (uint32_t)m, PWA_RLX_AGENT);
+                }
             }
         }
 

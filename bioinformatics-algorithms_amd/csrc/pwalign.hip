@@ -97,25 +97,43 @@ const BatchKernelEntry* find_batch_kernel(int R, int mode, int score) {
     return nullptr;
 }
 
-constexpr int kRL = 4;   // rows per lane of the wavefront (pair) engine
-
+// Geometry of the wavefront (pair) engine: RL rows per lane (stripe = 64*RL rows), CH steps per
+// hand-off chunk.  Short pairs get RL = 2 (twice the stripes = twice the waves in the pipeline).
 typedef void (*pair_kernel_t)(const PairParams);
-pair_kernel_t pair_fill_fn(bool local, bool tb, bool sband) {
-    if (local) {
-        if (tb) return sband ? pair_fill_kernel<kRL, true, true, true> : pair_fill_kernel<kRL, true, true, false>;
-        return pair_fill_kernel<kRL, true, false, false>;
-    }
-    if (tb) return sband ? pair_fill_kernel<kRL, false, true, true> : pair_fill_kernel<kRL, false, true, false>;
-    return pair_fill_kernel<kRL, false, false, false>;
+struct PairGeom {
+    int rl, ch;
+};
+PairGeom choose_geom(uint64_t max_n) {
+    PairGeom g{max_n <= 32768 ? 2 : 4, 16};
+    if (const char* e = std::getenv("PWA_FORCE_RL")) g.rl = std::atoi(e) == 2 ? 2 : 4;   // experiments only
+    if (const char* e = std::getenv("PWA_FORCE_CH")) g.ch = std::atoi(e) == 32 ? 32 : 16;
+    return g;
 }
-pair_kernel_t pair_tb_fn(bool local, bool walk) {
-    if (local) return walk ? pair_traceback_kernel<kRL, true, true> : pair_traceback_kernel<kRL, true, false>;
-    return walk ? pair_traceback_kernel<kRL, false, true> : pair_traceback_kernel<kRL, false, false>;
+template <int RL, int CH>
+pair_kernel_t pair_fill_pick(bool local, bool tb, bool sband) {
+    if (local) {
+        if (tb) return sband ? pair_fill_kernel<RL, CH, true, true, true> : pair_fill_kernel<RL, CH, true, true, false>;
+        return pair_fill_kernel<RL, CH, true, false, false>;
+    }
+    if (tb) return sband ? pair_fill_kernel<RL, CH, false, true, true> : pair_fill_kernel<RL, CH, false, true, false>;
+    return pair_fill_kernel<RL, CH, false, false, false>;
+}
+pair_kernel_t pair_fill_fn(PairGeom g, bool local, bool tb, bool sband) {
+    if (g.rl == 2) return g.ch == 32 ? pair_fill_pick<2, 32>(local, tb, sband) : pair_fill_pick<2, 16>(local, tb, sband);
+    return g.ch == 32 ? pair_fill_pick<4, 32>(local, tb, sband) : pair_fill_pick<4, 16>(local, tb, sband);
+}
+template <int RL>
+pair_kernel_t pair_tb_pick(bool local, bool walk) {
+    if (local) return walk ? pair_traceback_kernel<RL, true, true> : pair_traceback_kernel<RL, true, false>;
+    return walk ? pair_traceback_kernel<RL, false, true> : pair_traceback_kernel<RL, false, false>;
+}
+pair_kernel_t pair_tb_fn(PairGeom g, bool local, bool walk) {
+    return g.rl == 2 ? pair_tb_pick<2>(local, walk) : pair_tb_pick<4>(local, walk);
 }
 
-size_t tb_band_bytes(uint64_t n, uint64_t m) {
-    const uint64_t stripes = (n + 64 * kRL - 1) / (64 * kRL);
-    return (size_t)(stripes * (m + 63) * 64 * kRL);
+size_t tb_band_bytes(uint64_t n, uint64_t m, int rl) {
+    const uint64_t stripes = (n + 64 * rl - 1) / (64 * rl);
+    return (size_t)(stripes * (m + 63) * 64 * rl);
 }
 
 // Device-side state of one launch of the wavefront (pair) engine: pair descriptors, the global
@@ -123,11 +141,14 @@ size_t tb_band_bytes(uint64_t n, uint64_t m) {
 struct PairLaunch {
     DevBuf desc, tasks, rows, progress, best, queue;
     PairParams G{};
+    PairGeom geom{4, 16};
     uint32_t grid = 0;
     uint64_t row_bytes = 0;
 
     // pd[q].{pat,txt,n,m,tb,sband,res,ops,ops_cap} filled by the caller; this adds the pipeline fields
-    int build(pwa_ctx* ctx, std::vector<PairDesc>& pd, int match, int mismatch, int gap) {
+    int build(pwa_ctx* ctx, std::vector<PairDesc>& pd, int match, int mismatch, int gap, PairGeom g) {
+        geom = g;
+        const int kRL = g.rl;
         std::vector<StripeTask> tl;
         uint64_t rows_i32 = 0;
         for (size_t q = 0; q < pd.size(); ++q) {
@@ -172,10 +193,10 @@ struct PairLaunch {
     int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, bool walk, hipEvent_t after_fill, bool sband = false) {
         HIPC(ctx, hipMemsetAsync(queue.p, 0, 16, st));
         HIPC(ctx, hipMemsetAsync(progress.p, 0, progress.bytes, st));
-        hipLaunchKernelGGL(pair_fill_fn(local, tb, sband), dim3(grid), dim3(64), 0, st, G);
+        hipLaunchKernelGGL(pair_fill_fn(geom, local, tb, sband), dim3(grid), dim3(64), 0, st, G);
         HIPC(ctx, hipGetLastError());
         if (after_fill) HIPC(ctx, hipEventRecord(after_fill, st));
-        hipLaunchKernelGGL(pair_tb_fn(local, walk), dim3(G.n_pairs), dim3(64), 0, st, G);   // one wave per pair
+        hipLaunchKernelGGL(pair_tb_fn(geom, local, walk), dim3(G.n_pairs), dim3(64), 0, st, G);   // one wave per pair
         HIPC(ctx, hipGetLastError());
         return PWA_OK;
     }
@@ -523,6 +544,7 @@ int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, c
         b->live_idx = live;
         b->padded_cells = 0;
         std::vector<PairDesc> pd(nl);
+        const PairGeom geom = choose_geom(max_n);
         HIPC(ctx, b->pair_res.alloc(nl * sizeof(PairResult)));
         HIPC(ctx, hipMemset(b->pair_res.p, 0, nl * sizeof(PairResult)));
         for (size_t q = 0; q < nl; ++q) {
@@ -535,14 +557,14 @@ int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, c
             pd[q].res = b->pair_res.as<PairResult>() + q;
             pd[q].out_index = k;
             const uint64_t n = slen(pair_a[k]), m = slen(pair_b[k]);
-            b->padded_cells += (n + 64 * kRL - 1) / (64 * kRL) * (64 * kRL) * m;
+            b->padded_cells += (n + 64 * geom.rl - 1) / (64 * geom.rl) * (64 * geom.rl) * m;
         }
         {
-            const int rc = b->pl.build(ctx, pd, match, mismatch, gap);
+            const int rc = b->pl.build(ctx, pd, match, mismatch, gap, geom);
             if (rc != PWA_OK) return rc;
             b->pl.G.scores_out = b->scores.as<int32_t>();   // the device score vector is complete after run()
         }
-        b->kernel_name = local ? "pair_fill_kernel<RL=4,SW,no-traceback>" : "pair_fill_kernel<RL=4,NW,no-traceback>";
+        b->kernel_name = std::string("pair_fill_kernel<RL=") + std::to_string(geom.rl) + (local ? ",SW" : ",NW") + ",no-traceback>";
     }
     guard.b = nullptr;
     *out = b;
@@ -715,6 +737,10 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
         HIPC(ctx, hipMemcpy(arena.p, host_arena.data(), arena_bytes, hipMemcpyHostToDevice));
     }
 
+    uint64_t longest_n = 0;
+    for (uint64_t k = 0; k < n_pairs; ++k) longest_n = std::max(longest_n, slen(pair_a[k]));
+    const PairGeom geom = choose_geom(longest_n);
+    auto tb_band_bytes = [&](uint64_t n, uint64_t m) { return ::tb_band_bytes(n, m, geom.rl); };
     // pairs are processed in chunks whose traceback bands fit the free HBM
     size_t free_b = 0, total_b = 0;
     HIPC(ctx, hipMemGetInfo(&free_b, &total_b));
@@ -772,7 +798,7 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
         }
         HIPC(ctx, hipMemcpy(d_res.p, res.data(), nc * sizeof(PairResult), hipMemcpyHostToDevice));
         if (!pd.empty()) {
-            int rc = pl.build(ctx, pd, match, mismatch, gap);
+            int rc = pl.build(ctx, pd, match, mismatch, gap, geom);
             if (rc != PWA_OK) return rc;
             const bool dbg = std::getenv("PWA_DEBUG") != nullptr;
             if (dbg) std::fprintf(stderr, "[pwa] fill launch grid=%u pairs=%u tasks=%u band=%llu rows=%llu\n", pl.grid,
@@ -857,7 +883,9 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     }
     if (n == 0 || m == 0) return PWA_OK;
     HIPC(ctx, hipSetDevice(ctx->device));
-    const uint64_t band = tb_band_bytes(n, m);
+    const PairGeom geom = choose_geom(n);
+    const uint64_t kRL = (uint64_t)geom.rl;
+    const uint64_t band = tb_band_bytes(n, m, geom.rl);
     DevBuf d_pat, d_txt, d_band, d_sband, d_res;
     HIPC(ctx, d_pat.alloc(n + 64));
     HIPC(ctx, d_txt.alloc(m + 64));
@@ -877,7 +905,7 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     pd[0].sband = d_sband.as<int32_t>();
     pd[0].res = d_res.as<PairResult>();
     PairLaunch pl;
-    int rc = pl.build(ctx, pd, match, mismatch, gap);
+    int rc = pl.build(ctx, pd, match, mismatch, gap, geom);
     if (rc != PWA_OK) return rc;
     rc = pl.launch(ctx, ctx->stream, local, true, false, nullptr, true);
     if (rc != PWA_OK) return rc;
