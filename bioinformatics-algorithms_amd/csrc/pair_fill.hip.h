@@ -11,16 +11,19 @@
 //     c = t - k of its RL rows.  "left" and most "diag"/"up" operands are the lane's own registers;
 //     the row above a lane's first row comes from lane k-1 one step earlier through a DPP
 //     wave-shift (no LDS), as does the text character, which enters at lane 0 and travels down;
-//   * the stripes of one pair run CONCURRENTLY on different CUs as a software pipeline: stripe s
-//     consumes the bottom row of stripe s-1 a few CH-step chunks behind it (the producer's lane 63 is
-//     63 steps behind its lane 0, publication is deferred by one chunk so that no store drain sits in
-//     the loop, and the consumer polls / loads one chunk ahead of use).  The hand-off goes
-//     through a per-stripe row buffer in HBM: write-through (sc1) stores, the storing wave's
-//     vmcnt(0) drain, one sc1 progress-counter store by one lane; the consumer polls that counter
-//     with sc1 loads and reads the row with sc1 loads (cdna_hip_programming.md Guideline 16, R1 /
-//     MI355X_MICROARCH.md "valid forms", row 1).  Stripe tasks are dealt in global order from an
-//     atomic queue, so the producer of any task is always already running: no residency
-//     assumption, no deadlock for any grid size; every spin is bounded;
+//   * the stripes of one pair run CONCURRENTLY as a software pipeline.  A workgroup = W compute waves
+//     (W consecutive stripes, one wave per SIMD) + ONE helper wave.  Inside the workgroup stripe s+1
+//     consumes the bottom row of stripe s through a column-indexed ring in LDS, ~80 steps behind it
+//     (63 steps of lane skew + one 16-step chunk).  Between workgroups the row goes through HBM and
+//     ONLY the helper wave touches it: it polls the producer's column counter (sc1 loads), stages
+//     row + text into LDS rings, and in the other direction drains the last compute wave's output
+//     ring with write-through (sc1) stores, its own vmcnt(0), and one sc1 counter store
+//     (cdna_hip_programming.md Guideline 16, R1).  The compute waves therefore issue no vector-memory
+//     LOADS at all in their step loop -- only the fire-and-forget band stores -- so no s_waitcnt
+//     vmcnt ever sits on the DP's critical path (hipcc otherwise drains the band stores at every
+//     chunk boundary as soon as one load shares the loop).  Tasks (super-stripes) are dealt in
+//     global order from an atomic queue, so the producer of any task is always already running: no
+//     residency assumption, no deadlock for any grid size; every spin is bounded;
 //   * traceback codes (1 B/cell, the reference's char matrix) leave in SKEWED layout
 //     tb[stripe][step][lane][RL]: every step each wave stores 64*RL contiguous bytes (256 B for
 //     RL = 4); the optional int32 score band uses the same layout (1 KiB per step);
@@ -56,19 +59,20 @@ struct PairDesc {          // one pair of a launch
     int32_t n, m;
     uint8_t* tb;          // skewed traceback band (unused when the kernel is built without TB)
     int32_t* sband;       // optional skewed int32 score band (same indexing)
-    int32_t* rows;        // bottom rows of stripes 0 .. n_stripes-2, row_stride int32 each
+    int32_t* rows;        // bottom rows of super-stripes 0 .. n_super-2, row_stride int32 each
     PairResult* res;
     uint8_t* ops;         // traceback output, capacity ops_cap
     uint32_t ops_cap;
-    uint32_t first_task;  // index of this pair's stripe 0 in the task list
+    uint32_t first_task;  // index of this pair's super-stripe 0 in the task list
+    uint32_t first_stripe;// index of this pair's stripe 0 in PairParams::best
     uint32_t n_stripes;
     uint32_t row_stride;  // >= m + 64
     uint32_t out_index;   // slot of this pair in PairParams::scores_out
-    uint32_t pad;
+    uint32_t pad[3];
 };
 
-struct StripeTask {
-    uint32_t pair, stripe;
+struct StripeTask {       // one workgroup task: W consecutive stripes of one pair
+    uint32_t pair, super;
 };
 
 struct PairParams {
@@ -76,8 +80,8 @@ struct PairParams {
     const StripeTask* tasks;
     uint32_t n_pairs, n_tasks;
     uint32_t* queue;        // [0] atomic task counter, [1] error flag (both zeroed before every launch)
-    uint32_t* progress;     // per task: number of finished 64-step chunks (zeroed before every launch)
-    StripeBest* best;       // per task (SW)
+    uint32_t* progress;     // per task: bottom-row COLUMNS visible to other CUs (zeroed before every launch)
+    StripeBest* best;       // per stripe (SW)
     int32_t* scores_out;    // optional device score vector in caller order (nullptr: results only in PairResult)
     int32_t match, mismatch, gap;
 };
@@ -184,155 +188,210 @@ __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i
     }
 }
 
-template <int RL, int CH, bool LOCAL, bool TB, bool SBAND>
-__global__ __launch_bounds__(64) void pair_fill_kernel(const PairParams G) {
-    static_assert(CH == 16 || CH == 32, "chunk length");
-    const int lane = threadIdx.x;
+// ---- LDS flags between the waves of a workgroup: relaxed accesses + explicit lgkmcnt waits.  (A
+// workgroup-scope release/acquire would also order global memory, i.e. put a vmcnt(0) drain of the
+// band stores back into the step loop.)
+typedef __attribute__((address_space(3))) uint32_t l_u32;
+__device__ __forceinline__ uint32_t lds_peek(uint32_t* p) {
+    const uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");   // data reads stay below the flag read
+    return v;
+}
+__device__ __forceinline__ void lds_post(uint32_t* p, uint32_t v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS data accesses are done (LDS is in-order per wave)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+constexpr int kCH = 16;      // steps per hand-off chunk
+constexpr int kRing = 128;   // columns per LDS row ring (8 chunks)
+constexpr int kTRing = 4096; // text bytes staged in LDS
+
+template <int W>
+struct WgShared {
+    int ring[W + 1][kRing];       // ring[w]: row above compute wave w; ring[W]: bottom row of the last wave
+    uint8_t text[kTRing];
+    uint32_t ready[W + 1];        // columns written into ring[w]
+    uint32_t taken[W + 1];        // columns consumed from ring[w]
+    uint32_t txt_ready;
+    uint32_t task;
+};
+
+template <int RL, int W, bool LOCAL, bool TB, bool SBAND>
+__global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParams G) {
+    constexpr int CH = kCH;
+    __shared__ WgShared<W> sh;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int match = G.match, mismatch = G.mismatch, gap = G.gap;
+    const uint32_t spin_limit = 1u << 26;
     for (;;) {
-        uint32_t tid = 0;
-        {
-            // see batch_scores.hip.h: the electing lane id must be opaque on every trip
-            int elect = lane;
-            asm volatile("" : "+v"(elect));
-            if (elect == 0) tid = atomicAdd(G.queue, 1u);
+        __syncthreads();   // everybody is done with the previous task's LDS state
+        if (threadIdx.x == 0) sh.task = atomicAdd(G.queue, 1u);
+        if (threadIdx.x < 2 * (W + 1) + 1) {
+            if (threadIdx.x <= W) sh.ready[threadIdx.x] = 0;
+            else if (threadIdx.x <= 2 * W + 1) sh.taken[threadIdx.x - (W + 1)] = 0;
+            else sh.txt_ready = 0;
         }
-        tid = __builtin_amdgcn_readfirstlane(tid);
+        __syncthreads();
+        const uint32_t tid = __builtin_amdgcn_readfirstlane(sh.task);
         if (tid >= G.n_tasks) break;
         const StripeTask task = G.tasks[tid];
         const PairDesc P = G.pairs[task.pair];
-        const int s = (int)task.stripe;
+        const int ss = (int)task.super;
         const int n = P.n, m = P.m;
         const int T = m + 63;
         const int n_chunks = (T + CH - 1) / CH;
-        const bool has_top = s > 0;
-        const bool has_bot = (uint32_t)(s + 1) < P.n_stripes;
-
-        const int i_first = s * 64 * RL + lane * RL + 1;   // first row of this lane (1-based)
-        int pc[RL], hl[RL], bs[RL], bj[RL];
-#pragma unroll
-        for (int r = 0; r < RL; ++r) {
-            const int i = i_first + r;
-            pc[r] = (i <= n) ? (int)((g_cu8*)P.pat)[i - 1] : 256;   // 256 never equals a text byte
-            hl[r] = LOCAL ? 0 : p_mulw(i, gap);           // dp[i][0], hw2.cpp:125-130
-            bs[r] = 0;
-            bj[r] = 0;
-        }
-        int diag0 = LOCAL ? 0 : p_mulw(i_first - 1, gap);   // dp[i_first-1][0]
-        g_i32* rin = (g_i32*)(P.rows + (size_t)(has_top ? s - 1 : 0) * P.row_stride);
-        g_i32* rout = (g_i32*)(P.rows + (size_t)s * P.row_stride);
-        g_u8* tbs = TB ? (g_u8*)(P.tb + (size_t)s * T * 64 * RL) : nullptr;
-        g_i32* sbs = SBAND ? (g_i32*)(P.sband + (size_t)s * T * 64 * RL) : nullptr;
+        const int n_super = ((int)P.n_stripes + W - 1) / W;
+        const bool top_global = ss > 0, bot_global = ss + 1 < n_super;
+        const int wl = min(W - 1, (int)P.n_stripes - 1 - ss * W);   // last active compute wave
         g_cu8* txt = (g_cu8*)P.txt;
-        PWA_GLOBAL PairResult* res = (PWA_GLOBAL PairResult*)P.res;
-        // progress word of a stripe = number of bottom-row COLUMNS that are visible to other CUs
-        g_u32* prog_in = (g_u32*)(G.progress + (has_top ? tid - 1 : tid));   // previous stripe of the same pair
-        g_u32* prog_out = (g_u32*)(G.progress + tid);
 
-        int bottom = 0, tch = 0, coll = 0;
-        // consumer-side run-ahead: the producer's counter is polled one chunk early and, when it already
-        // covers the next chunk, that chunk's row is loaded one chunk early -- in steady state neither the
-        // poll's nor the row load's latency is on the critical path (it only lengthens the pipeline lag)
-        uint32_t pub_seen = 0;
-        int row_next = 0, txt_next = (lane < CH && lane < m) ? (int)txt[lane] : 0;
-        bool row_next_valid = false;
-        for (int ch = 0; ch < n_chunks; ++ch) {
-            const int t0 = ch * CH;
-            // ---- the row above the stripe and the text for columns t0 .. t0+CH-1 (lanes 0 .. CH-1)
-            int topv = 0;
-            const int c0 = t0 + lane;
-            if (has_top) {
-                if (row_next_valid) {
-                    topv = row_next;
-                } else {
-                    const uint32_t need = (uint32_t)min(m, t0 + CH);
-                    uint32_t spins = 0;
-                    while ((pub_seen = __hip_atomic_load(prog_in, PWA_RLX_AGENT)) < need) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > (1u << 24)) {   // bounded spin: flag the failure and go on with junk
-                            if (lane == 0) __hip_atomic_store((g_u32*)(G.queue + 1), 1u, PWA_RLX_AGENT);
-                            break;
+        if (wave == W) {
+            // =================== helper wave: every global-memory hand-off of this workgroup ===================
+            g_i32* rin = (g_i32*)(P.rows + (size_t)(top_global ? ss - 1 : 0) * P.row_stride);
+            g_i32* rout = (g_i32*)(P.rows + (size_t)ss * P.row_stride);
+            g_u32* prog_in = (g_u32*)(G.progress + (top_global ? tid - 1 : tid));   // previous super-stripe, same pair
+            g_u32* prog_out = (g_u32*)(G.progress + tid);
+            int kin = 0, kout = 0;
+            uint32_t idle = 0;
+            for (;;) {
+                const bool done_in = kin >= m, done_out = !bot_global || kout >= m;
+                if (done_in && done_out) break;
+                bool progress = false;
+                if (!done_in) {   // ---- stage text + the row above wave 0, up to 64 columns per trip
+                    int lim = min(m, min((int)lds_peek(&sh.taken[0]) + kRing, (int)lds_peek(&sh.taken[wl]) + kTRing));
+                    if (top_global) lim = min(lim, (int)__hip_atomic_load(prog_in, PWA_RLX_AGENT));   // sc1 poll
+                    const int hi = min(lim, kin + 64);
+                    if (hi > kin) {
+                        const int c = kin + lane;
+                        if (c < hi) {
+                            int v;
+                            if (top_global) v = __hip_atomic_load(rin + c, PWA_RLX_AGENT);   // sc1: issued after the poll's value is known
+                            else v = LOCAL ? 0 : p_mulw(c + 1, gap);                         // dp[0][j], hw2.cpp:131-136
+                            sh.ring[0][c % kRing] = v;
+                            sh.text[c % kTRing] = txt[c];
                         }
+                        lds_post(&sh.ready[0], (uint32_t)hi);
+                        lds_post(&sh.txt_ready, (uint32_t)hi);
+                        kin = hi;
+                        progress = true;
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // compiler-only: row loads stay below the poll
-                    if (lane < CH && c0 < m) topv = __hip_atomic_load(rin + c0, PWA_RLX_AGENT);   // sc1 load
                 }
-            } else if (!LOCAL) {
-                topv = p_mulw(c0 + 1, gap);   // dp[0][j], hw2.cpp:131-136
-            }
-            int tcv = txt_next;
-            {   // ---- run-ahead for chunk ch+1
-                const int cn = t0 + CH + lane;
-                txt_next = (lane < CH && cn < m) ? (int)txt[cn] : 0;
-                row_next_valid = false;
-                if (has_top && ch + 1 < n_chunks) {
-                    const uint32_t need_n = (uint32_t)min(m, t0 + 2 * CH);
-                    if (pub_seen >= need_n) {   // known from a poll that completed before this load is issued
-                        row_next = (lane < CH && cn < m) ? __hip_atomic_load(rin + cn, PWA_RLX_AGENT) : 0;
-                        row_next_valid = true;
+                if (!done_out) {   // ---- publish the bottom row of the last wave
+                    const int hi = min((int)lds_peek(&sh.ready[W]), kout + 64);
+                    if (hi > kout) {
+                        const int c = kout + lane;
+                        if (c < hi) __hip_atomic_store(rout + c, sh.ring[W][c % kRing], PWA_RLX_AGENT);   // sc1 (write-through)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   // only this wave's own stores
+                        if (lane == 0) __hip_atomic_store(prog_out, (uint32_t)hi, PWA_RLX_AGENT);
+                        lds_post(&sh.taken[W], (uint32_t)hi);
+                        kout = hi;
+                        progress = true;
                     }
-                    pub_seen = __hip_atomic_load(prog_in, PWA_RLX_AGENT);   // consumed one chunk later
                 }
-            }
-            const bool interior = t0 >= 63 && t0 + CH < m;   // every lane inside the matrix, last column not touched
-            if (interior) {
-#pragma unroll 4
-                for (int q = 0; q < CH; ++q)
-                    stripe_step<RL, LOCAL, TB, SBAND, false>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
-                                                             tcv, coll, bs, bj, match, mismatch, gap, tbs, sbs, res);
-            } else {
-                const int qn = min(CH, T - t0);
-#pragma unroll 1
-                for (int q = 0; q < qn; ++q)
-                    stripe_step<RL, LOCAL, TB, SBAND, true>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
-                                                            tcv, coll, bs, bj, match, mismatch, gap, tbs, sbs, res);
-#pragma unroll 1
-                for (int q = qn; q < CH; ++q) coll = wave_shl1(bottom, coll);   // keep the collector aligned
-            }
-            // ---- bottom row out: after the chunk lane 64-CH+q holds column t0 - 63 + q
-            if (has_bot) {
-                const int c = t0 - 63 + (lane - (64 - CH));
-                if (lane >= 64 - CH && c >= 0 && c < m) __hip_atomic_store(rout + c, coll, PWA_RLX_AGENT);   // sc1 (write-through)
-                if (ch + 1 < n_chunks) {
-                    // Deferred publication: do not drain this chunk's stores.  Once at most (TB ? CH : 0) + 1
-                    // younger operations are outstanding, the row store of the PREVIOUS chunk has completed
-                    // (vmcnt retires loads and stores in issue order), i.e. columns < t0 - 63 are visible.
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"i"((TB && !SBAND ? CH : 0) + 1) : "memory");
-                    const int pubv = min(m, t0 - 63);
-                    if (lane == 0 && pubv > 0) __hip_atomic_store(prog_out, (uint32_t)pubv, PWA_RLX_AGENT);
+                if (progress) {
+                    idle = 0;
                 } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(prog_out, (uint32_t)m, PWA_RLX_AGENT);
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++idle > spin_limit) {   // bounded: flag the failure, let the host report it
+                        if (lane == 0) __hip_atomic_store((g_u32*)(G.queue + 1), 1u, PWA_RLX_AGENT);
+                        break;
+                    }
                 }
             }
-        }
-
-        if (LOCAL) {
-            // per-lane reduction over row slots, then over the wave: max score, then smallest i
-            int s_best = 0, i_best = 0, j_best = 0;
+        } else if (wave <= wl) {
+            // =================== compute wave `wave`: stripe ss*W + wave ===================
+            const int s = ss * W + wave;
+            const bool has_out = wave < wl || (wave == W - 1 && bot_global);
+            const int i_first = s * 64 * RL + lane * RL + 1;   // first row of this lane (1-based)
+            int pc[RL], hl[RL], bs[RL], bj[RL];
 #pragma unroll
             for (int r = 0; r < RL; ++r) {
                 const int i = i_first + r;
-                if (i <= n && bs[r] > s_best) {   // slots in increasing i: strict '>' keeps the smallest i
-                    s_best = bs[r];
-                    i_best = i;
-                    j_best = bj[r];
+                pc[r] = (i <= n) ? (int)((g_cu8*)P.pat)[i - 1] : 256;   // 256 never equals a text byte
+                hl[r] = LOCAL ? 0 : p_mulw(i, gap);                     // dp[i][0], hw2.cpp:125-130
+                bs[r] = 0;
+                bj[r] = 0;
+            }
+            int diag0 = LOCAL ? 0 : p_mulw(i_first - 1, gap);           // dp[i_first-1][0]
+            g_u8* tbs = TB ? (g_u8*)(P.tb + (size_t)s * T * 64 * RL) : nullptr;
+            g_i32* sbs = SBAND ? (g_i32*)(P.sband + (size_t)s * T * 64 * RL) : nullptr;
+            PWA_GLOBAL PairResult* res = (PWA_GLOBAL PairResult*)P.res;
+            int* rin = sh.ring[wave];
+            int* rout = sh.ring[wave + 1];
+            int bottom = 0, tch = 0, coll = 0;
+            bool failed = false;
+            for (int ch = 0; ch < n_chunks; ++ch) {
+                const int t0 = ch * CH;
+                // ---- wait for the row above and the text of columns t0 .. t0+CH-1, then take them
+                const uint32_t need = (uint32_t)min(m, t0 + CH);
+                for (uint32_t spins = 0; !failed && (lds_peek(&sh.ready[wave]) < need || lds_peek(&sh.txt_ready) < need);) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > spin_limit) failed = true;
+                }
+                const int c0 = t0 + lane;
+                int topv = 0, tcv = 0;
+                if (lane < CH && c0 < m) {
+                    topv = rin[c0 % kRing];
+                    tcv = sh.text[c0 % kTRing];
+                }
+                lds_post(&sh.taken[wave], need);
+                const bool interior = t0 >= 63 && t0 + CH < m;   // every lane inside the matrix, last column not touched
+                if (interior) {
+#pragma unroll 4
+                    for (int q = 0; q < CH; ++q)
+                        stripe_step<RL, LOCAL, TB, SBAND, false>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
+                                                                 tcv, coll, bs, bj, match, mismatch, gap, tbs, sbs, res);
+                } else {
+                    const int qn = min(CH, T - t0);
+#pragma unroll 1
+                    for (int q = 0; q < qn; ++q)
+                        stripe_step<RL, LOCAL, TB, SBAND, true>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
+                                                                tcv, coll, bs, bj, match, mismatch, gap, tbs, sbs, res);
+#pragma unroll 1
+                    for (int q = qn; q < CH; ++q) coll = wave_shl1(bottom, coll);   // keep the collector aligned
+                }
+                // ---- bottom row out: after the chunk lane 64-CH+q holds column t0 - 63 + q
+                if (has_out) {
+                    const int hi = min(m, t0 - 63 + CH);
+                    if (hi > 0) {
+                        for (uint32_t spins = 0; !failed && hi - (int)lds_peek(&sh.taken[wave + 1]) > kRing;) {   // ring full
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > spin_limit) failed = true;
+                        }
+                        const int c = t0 - 63 + (lane - (64 - CH));
+                        if (lane >= 64 - CH && c >= 0 && c < m) rout[c % kRing] = coll;
+                        lds_post(&sh.ready[wave + 1], (uint32_t)hi);
+                    }
                 }
             }
+            if (failed && lane == 0) __hip_atomic_store((g_u32*)(G.queue + 1), 1u, PWA_RLX_AGENT);
+
+            if (LOCAL) {
+                // per-lane reduction over row slots, then over the wave: max score, then smallest i
+                int s_best = 0, i_best = 0, j_best = 0;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const int so = __shfl_xor(s_best, off), io = __shfl_xor(i_best, off), jo = __shfl_xor(j_best, off);
-                const bool better = so > s_best || (so == s_best && so > 0 && io < i_best);
-                if (better) { s_best = so; i_best = io; j_best = jo; }
-            }
-            int wr = lane;
-            asm volatile("" : "+v"(wr));   // opaque for the same reason as `elect` above
-            if (wr == 0) {
-                g_i32* bp = (g_i32*)(G.best + tid);
-                bp[0] = s_best;
-                bp[1] = i_best;
-                bp[2] = j_best;
-                bp[3] = 0;
+                for (int r = 0; r < RL; ++r) {
+                    const int i = i_first + r;
+                    if (i <= n && bs[r] > s_best) {   // slots in increasing i: strict '>' keeps the smallest i
+                        s_best = bs[r];
+                        i_best = i;
+                        j_best = bj[r];
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const int so = __shfl_xor(s_best, off), io = __shfl_xor(i_best, off), jo = __shfl_xor(j_best, off);
+                    const bool better = so > s_best || (so == s_best && so > 0 && io < i_best);
+                    if (better) { s_best = so; i_best = io; j_best = jo; }
+                }
+                if (lane == 0) {
+                    g_i32* bp = (g_i32*)(G.best + P.first_stripe + s);
+                    bp[0] = s_best;
+                    bp[1] = i_best;
+                    bp[2] = j_best;
+                    bp[3] = 0;
+                }
             }
         }
     }
@@ -367,7 +426,7 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         i = 0;
         j = 0;
         for (uint32_t s = 0; s < P.n_stripes; ++s) {   // stripes in increasing i: strict '>' = first row-major maximum
-            const PWA_GLOBAL StripeBest* b = (const PWA_GLOBAL StripeBest*)(G.best + P.first_task + s);
+            const PWA_GLOBAL StripeBest* b = (const PWA_GLOBAL StripeBest*)(G.best + P.first_stripe + s);
             const int sc = b->score;
             if (sc > sb) {
                 sb = sc;

@@ -97,30 +97,32 @@ const BatchKernelEntry* find_batch_kernel(int R, int mode, int score) {
     return nullptr;
 }
 
-// Geometry of the wavefront (pair) engine: RL rows per lane (stripe = 64*RL rows), CH steps per
-// hand-off chunk.  Short pairs get RL = 2 (twice the stripes = twice the waves in the pipeline).
+// Geometry of the wavefront (pair) engine: RL rows per lane (stripe = 64*RL rows) and W compute waves
+// per workgroup (a workgroup task = W consecutive stripes + one helper wave).  Pairs of a single
+// stripe use W = 1; short multi-stripe pairs get RL = 2 (twice the stripes = twice the waves in flight).
 typedef void (*pair_kernel_t)(const PairParams);
 struct PairGeom {
-    int rl, ch;
+    int rl, w;
 };
 PairGeom choose_geom(uint64_t max_n) {
-    PairGeom g{max_n <= 32768 ? 2 : 4, 16};
+    PairGeom g{max_n <= 32768 ? 2 : 4, 4};   // [gpu] 10k x 10k: RL=2 2.27 ms vs RL=4 2.52; 100k x 100k: RL=4 20.9 ms vs RL=2 22.0
     if (const char* e = std::getenv("PWA_FORCE_RL")) g.rl = std::atoi(e) == 2 ? 2 : 4;   // experiments only
-    if (const char* e = std::getenv("PWA_FORCE_CH")) g.ch = std::atoi(e) == 32 ? 32 : 16;
+    if ((max_n + 64 * g.rl - 1) / (64 * g.rl) <= 1) g.w = 1;
+    if (const char* e = std::getenv("PWA_FORCE_W")) g.w = std::atoi(e) == 1 ? 1 : 4;
     return g;
 }
-template <int RL, int CH>
+template <int RL, int W>
 pair_kernel_t pair_fill_pick(bool local, bool tb, bool sband) {
     if (local) {
-        if (tb) return sband ? pair_fill_kernel<RL, CH, true, true, true> : pair_fill_kernel<RL, CH, true, true, false>;
-        return pair_fill_kernel<RL, CH, true, false, false>;
+        if (tb) return sband ? pair_fill_kernel<RL, W, true, true, true> : pair_fill_kernel<RL, W, true, true, false>;
+        return pair_fill_kernel<RL, W, true, false, false>;
     }
-    if (tb) return sband ? pair_fill_kernel<RL, CH, false, true, true> : pair_fill_kernel<RL, CH, false, true, false>;
-    return pair_fill_kernel<RL, CH, false, false, false>;
+    if (tb) return sband ? pair_fill_kernel<RL, W, false, true, true> : pair_fill_kernel<RL, W, false, true, false>;
+    return pair_fill_kernel<RL, W, false, false, false>;
 }
 pair_kernel_t pair_fill_fn(PairGeom g, bool local, bool tb, bool sband) {
-    if (g.rl == 2) return g.ch == 32 ? pair_fill_pick<2, 32>(local, tb, sband) : pair_fill_pick<2, 16>(local, tb, sband);
-    return g.ch == 32 ? pair_fill_pick<4, 32>(local, tb, sband) : pair_fill_pick<4, 16>(local, tb, sband);
+    if (g.rl == 2) return g.w == 1 ? pair_fill_pick<2, 1>(local, tb, sband) : pair_fill_pick<2, 4>(local, tb, sband);
+    return g.w == 1 ? pair_fill_pick<4, 1>(local, tb, sband) : pair_fill_pick<4, 4>(local, tb, sband);
 }
 template <int RL>
 pair_kernel_t pair_tb_pick(bool local, bool walk) {
@@ -141,38 +143,43 @@ size_t tb_band_bytes(uint64_t n, uint64_t m, int rl) {
 struct PairLaunch {
     DevBuf desc, tasks, rows, progress, best, queue;
     PairParams G{};
-    PairGeom geom{4, 16};
+    PairGeom geom{4, 4};
     uint32_t grid = 0;
     uint64_t row_bytes = 0;
 
     // pd[q].{pat,txt,n,m,tb,sband,res,ops,ops_cap} filled by the caller; this adds the pipeline fields
     int build(pwa_ctx* ctx, std::vector<PairDesc>& pd, int match, int mismatch, int gap, PairGeom g) {
         geom = g;
-        const int kRL = g.rl;
+        const uint64_t rows_per_stripe = 64ull * g.rl;
         std::vector<StripeTask> tl;
-        uint64_t rows_i32 = 0;
+        uint64_t rows_i32 = 0, n_stripes_total = 0;
         for (size_t q = 0; q < pd.size(); ++q) {
-            const uint64_t ns = ((uint64_t)pd[q].n + 64 * kRL - 1) / (64 * kRL);
-            if (tl.size() + ns >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "too many stripe tasks in one launch");
+            const uint64_t ns = ((uint64_t)pd[q].n + rows_per_stripe - 1) / rows_per_stripe;
+            const uint64_t nsup = (ns + g.w - 1) / g.w;
+            if (tl.size() + nsup >= 0xffffffffull || n_stripes_total + ns >= 0xffffffffull)
+                return fail(ctx, PWA_E_CAPACITY, "too many stripe tasks in one launch");
             pd[q].first_task = (uint32_t)tl.size();
+            pd[q].first_stripe = (uint32_t)n_stripes_total;
             pd[q].n_stripes = (uint32_t)ns;
             pd[q].row_stride = (uint32_t)align_up((uint64_t)pd[q].m + 64, 64);
-            for (uint64_t st = 0; st < ns; ++st) tl.push_back({(uint32_t)q, (uint32_t)st});
-            rows_i32 += (ns - 1) * pd[q].row_stride;
+            for (uint64_t st = 0; st < nsup; ++st) tl.push_back({(uint32_t)q, (uint32_t)st});
+            rows_i32 += (nsup - 1) * pd[q].row_stride;
+            n_stripes_total += ns;
         }
         row_bytes = rows_i32 * sizeof(int32_t);
         HIPC(ctx, rows.alloc(row_bytes));
         uint64_t ro = 0;
         for (auto& d : pd) {
             d.rows = rows.as<int32_t>() + ro;
-            ro += (uint64_t)(d.n_stripes - 1) * d.row_stride;
+            const uint64_t nsup = ((uint64_t)d.n_stripes + g.w - 1) / g.w;
+            ro += (nsup - 1) * d.row_stride;
         }
         HIPC(ctx, desc.alloc(pd.size() * sizeof(PairDesc)));
         HIPC(ctx, hipMemcpy(desc.p, pd.data(), pd.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
         HIPC(ctx, tasks.alloc(tl.size() * sizeof(StripeTask)));
         HIPC(ctx, hipMemcpy(tasks.p, tl.data(), tl.size() * sizeof(StripeTask), hipMemcpyHostToDevice));
         HIPC(ctx, progress.alloc(align_up(tl.size() * sizeof(uint32_t), 16)));
-        HIPC(ctx, best.alloc(tl.size() * sizeof(StripeBest)));
+        HIPC(ctx, best.alloc(std::max<uint64_t>(n_stripes_total, 1) * sizeof(StripeBest)));
         HIPC(ctx, queue.alloc(64));
         G.pairs = desc.as<PairDesc>();
         G.tasks = tasks.as<StripeTask>();
@@ -184,16 +191,16 @@ struct PairLaunch {
         G.match = match;
         G.mismatch = mismatch;
         G.gap = gap;
-        // Tasks come off the queue in global order, so correctness does not depend on how many waves are
-        // resident; 8 single-wave workgroups per CU keep every SIMD at two waves.
-        grid = (uint32_t)std::min<uint64_t>(tl.size(), (uint64_t)ctx->num_cu * 8);
+        // Tasks come off the queue in global order, so correctness does not depend on how many workgroups
+        // are resident.  One workgroup = W compute waves + 1 helper wave.
+        grid = (uint32_t)std::min<uint64_t>(tl.size(), (uint64_t)ctx->num_cu * (g.w == 1 ? 8 : 3));
         return PWA_OK;
     }
     // enqueue: zero the queue / progress words, fill, then the walk (or only the end-cell pick)
     int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, bool walk, hipEvent_t after_fill, bool sband = false) {
         HIPC(ctx, hipMemsetAsync(queue.p, 0, 16, st));
         HIPC(ctx, hipMemsetAsync(progress.p, 0, progress.bytes, st));
-        hipLaunchKernelGGL(pair_fill_fn(geom, local, tb, sband), dim3(grid), dim3(64), 0, st, G);
+        hipLaunchKernelGGL(pair_fill_fn(geom, local, tb, sband), dim3(grid), dim3(64 * (geom.w + 1)), 0, st, G);
         HIPC(ctx, hipGetLastError());
         if (after_fill) HIPC(ctx, hipEventRecord(after_fill, st));
         hipLaunchKernelGGL(pair_tb_fn(geom, local, walk), dim3(G.n_pairs), dim3(64), 0, st, G);   // one wave per pair
