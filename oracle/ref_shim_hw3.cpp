@@ -1,0 +1,16 @@
+// ref_shim_hw3.cpp -- TEST INFRASTRUCTURE ONLY (dev container only).
+// Builds the UNMODIFIED /root/reference/Multiple_Sequence_Alignment/hw3.cpp (textual inclusion at
+// compile time via -DHW3_REF_SRC=...; nothing is copied) into oracle/_ref/libhw3_ref.so and exposes
+// the score pass of affine_alignment (hw3.cpp:23-102) and main (169) through a C ABI.
+#define main hw3_reference_main
+#include HW3_REF_SRC
+#undef main
+
+extern "C" {
+int ref3_affine_score(const char* s1, size_t n, const char* s2, size_t m, int match, int mismatch, int go, int ge) {
+    int score = 0;
+    affine_alignment(std::string(s1, n), std::string(s2, m), match, mismatch, go, ge, &score);
+    return score;
+}
+int ref3_main(int argc, char** argv) { return hw3_reference_main(argc, argv); }
+}

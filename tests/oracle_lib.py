@@ -13,6 +13,9 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle_hw2.so")
 ORACLE_CLI = os.path.join(ORACLE_DIR, "hw2_oracle_cli")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libhw2_ref.so")
 REF_CLI = os.path.join(ORACLE_DIR, "_ref", "hw2_ref")
+ORACLE3_SO = os.path.join(ORACLE_DIR, "liboracle_hw3.so")
+REF3_SO = os.path.join(ORACLE_DIR, "_ref", "libhw3_ref.so")
+REF3_CLI = os.path.join(ORACLE_DIR, "_ref", "hw3_ref")
 
 
 class _OrcResult(C.Structure):
@@ -189,3 +192,70 @@ def run_cli(exe, args, cwd=None):
     """Run a hw2-compatible CLI; returns (rc, stderr bytes)."""
     pr = subprocess.run([exe] + [str(a) for a in args], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     return pr.returncode, pr.stderr
+
+
+# ---------------------------------------------------------------------------- hw3 affine score pass
+_lib3 = None
+_ref3 = None
+_SIG3 = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int]
+
+
+def oracle3():
+    global _lib3
+    if _lib3 is None:
+        if not os.path.exists(ORACLE3_SO):
+            build_oracle(with_ref=False)
+        lib = C.CDLL(ORACLE3_SO)
+        lib.orc3_affine_score.argtypes = _SIG3
+        lib.orc3_affine_score.restype = C.c_int32
+        lib.orc3_center.argtypes = [C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_int64)]
+        lib.orc3_center.restype = C.c_size_t
+        _lib3 = lib
+    return _lib3
+
+
+def have_ref3():
+    return os.path.exists(REF3_SO)
+
+
+def affine_score(s1, s2, match, mismatch, go, ge):
+    """Oracle: hw3.cpp affine_alignment score (max of V, F, E at (n, m))."""
+    s1, s2 = _as_bytes(s1), _as_bytes(s2)
+    return oracle3().orc3_affine_score(s1, len(s1), s2, len(s2), match, mismatch, go, ge)
+
+
+def ref_affine_score(s1, s2, match, mismatch, go, ge):
+    """The unmodified hw3.cpp function (dev container only)."""
+    global _ref3
+    if _ref3 is None:
+        _ref3 = C.CDLL(REF3_SO)
+        _ref3.ref3_affine_score.argtypes = _SIG3
+        _ref3.ref3_affine_score.restype = C.c_int
+    s1, s2 = _as_bytes(s1), _as_bytes(s2)
+    return _ref3.ref3_affine_score(s1, len(s1), s2, len(s2), match, mismatch, go, ge)
+
+
+def center(pair_scores_upper, n_seq):
+    """hw3.cpp:230-251: (center index, star scores)."""
+    arr = (C.c_int32 * max(len(pair_scores_upper), 1))(*pair_scores_upper)
+    sums = (C.c_int64 * n_seq)()
+    c = oracle3().orc3_center(arr, n_seq, sums)
+    return c, list(sums)
+
+
+def read_fasta_hw3(path):
+    """hw3.cpp:137-167 readFASTA: (header, sequence) records; whitespace inside lines dropped."""
+    recs, header, seq = [], None, b""
+    for line in open(path, "rb").read().split(b"\n"):
+        if not line:
+            continue
+        if line[:1] == b">":
+            if header:
+                recs.append((header, seq))
+                seq = b""
+            header = line[1:]
+        else:
+            seq += bytes(ch for ch in line if ch not in b" \t\n\v\f\r")
+    if header:
+        recs.append((header, seq))
+    return recs
