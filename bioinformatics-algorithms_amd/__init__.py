@@ -24,7 +24,7 @@ MODE = {"nw": 0, "sw": 1, "global": 0, "local": 1}
 
 EXPORTS = [
     "pwa_version", "pwa_strerror", "pwa_ctx_create", "pwa_ctx_destroy", "pwa_last_error", "pwa_scores",
-    "pwa_batch_create", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_set_d_scores", "pwa_batch_fetch", "pwa_batch_info",
+    "pwa_batch_create", "pwa_affine_batch_create", "pwa_scores_affine", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_set_d_scores", "pwa_batch_fetch", "pwa_batch_info",
     "pwa_batch_last_ms", "pwa_batch_run_times", "pwa_batch_destroy", "pwa_align", "pwa_align_matrices", "pwa_align_last_stats", "pwa_align_batch",
     "pwa_cigar_bound", "pwa_mdz_bound", "pwa_format_alignment",
 ]
@@ -58,6 +58,9 @@ def lib():
     batch_in = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, u64p, C.c_uint32, u32p, u32p, C.c_uint64]
     L.pwa_scores.argtypes = batch_in + [i32p, u32p, u32p]
     L.pwa_batch_create.argtypes = batch_in + [C.c_int, C.POINTER(vp)]
+    affine_in = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, u64p, C.c_uint32, u32p, u32p, C.c_uint64]
+    L.pwa_affine_batch_create.argtypes = affine_in + [C.POINTER(vp)]
+    L.pwa_scores_affine.argtypes = affine_in + [i32p]
     L.pwa_batch_run.argtypes = [vp, vp]
     L.pwa_batch_d_scores.argtypes = [vp]
     L.pwa_batch_d_scores.restype = vp
@@ -164,6 +167,17 @@ class Context:
     def batch(self, mode, seqs, pair_a, pair_b, match, mismatch, gap, want_end=False):
         return Batch(self, mode, seqs, pair_a, pair_b, match, mismatch, gap, want_end)
 
+    # -- hw3.cpp affine_alignment score pass (hw3.cpp:23-102, all-pairs loop 232-241)
+    def scores_affine(self, seqs, pair_a, pair_b, match, mismatch, gap_open, gap_extend):
+        b = Batch(self, "affine", seqs, pair_a, pair_b, match, mismatch, gap_open, gap_extend=gap_extend)
+        b.run()
+        out = b.fetch()
+        b.close()
+        return out
+
+    def batch_affine(self, seqs, pair_a, pair_b, match, mismatch, gap_open, gap_extend):
+        return Batch(self, "affine", seqs, pair_a, pair_b, match, mismatch, gap_open, gap_extend=gap_extend)
+
     # -- one full alignment = one call of hw2.cpp:118 / 192
     def align(self, mode, pattern, text, match, mismatch, gap, raw=False):
         pattern, text = _b(pattern), _b(text)
@@ -227,7 +241,7 @@ class Context:
 class Batch:
     """Prepared scores-only batch: inputs resident in HBM, run() only enqueues kernels."""
 
-    def __init__(self, ctx, mode, seqs, pair_a, pair_b, match, mismatch, gap, want_end=False):
+    def __init__(self, ctx, mode, seqs, pair_a, pair_b, match, mismatch, gap, want_end=False, gap_extend=0):
         self._ctx, self._L = ctx, ctx._L
         blob, off, seqs = pack_sequences(seqs)
         self.n_pairs = len(pair_a)
@@ -240,8 +254,12 @@ class Batch:
             pa = (C.c_uint32 * max(n, 1))(*pair_a)
             pb = (C.c_uint32 * max(n, 1))(*pair_b)
         h = C.c_void_p()
-        rc = self._L.pwa_batch_create(ctx._h, MODE[mode], match, mismatch, gap, blob, off, len(seqs), pa, pb, n,
-                                      1 if want_end else 0, C.byref(h))
+        if mode == "affine":
+            rc = self._L.pwa_affine_batch_create(ctx._h, match, mismatch, gap, gap_extend, blob, off, len(seqs), pa, pb, n,
+                                                 C.byref(h))
+        else:
+            rc = self._L.pwa_batch_create(ctx._h, MODE[mode], match, mismatch, gap, blob, off, len(seqs), pa, pb, n,
+                                          1 if want_end else 0, C.byref(h))
         ctx._check(rc, "pwa_batch_create")
         self._h = h
         self.want_end = want_end

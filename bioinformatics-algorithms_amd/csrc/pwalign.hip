@@ -8,12 +8,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <numeric>
 #include <string>
 #include <vector>
 
 #include "batch_scores.hip.h"
+#include "batch_affine.hip.h"
 #include "pair_fill.hip.h"
 
 using namespace pwa;
@@ -74,10 +76,13 @@ inline int32_t wrap_mul(int64_t a, int32_t b) { return (int32_t)((uint32_t)a * (
 
 // --------------------------------------------------------------------------- kernel tables
 typedef void (*batch_kernel_t)(const BatchParams);
+typedef void (*affine_kernel_t)(const AffineParams);
+enum { BM_AFF = 3, BM_AFFS = 4 };   // affine (hw3) plain / Ge(i+j)-shifted; modes 0..2 are in batch_scores.hip.h
 struct BatchKernelEntry {
     int R, mode, score;
     batch_kernel_t fn;
     const char* name;
+    affine_kernel_t afn = nullptr;
 };
 #define BK(R, M, S) {R, M, S, batch_scores_kernel<R, M, S>, "batch_scores_kernel<R=" #R "," #M "," #S ">"}
 const BatchKernelEntry kBatchKernels[] = {
@@ -88,6 +93,10 @@ const BatchKernelEntry kBatchKernels[] = {
     BK(64, BM_NW, SC_CMP),    BK(128, BM_NW, SC_CMP),   BK(152, BM_NW, SC_CMP),
     BK(64, BM_NWG, SC_PERM),  BK(128, BM_NWG, SC_PERM), BK(152, BM_NWG, SC_PERM),
     BK(64, BM_NWG, SC_CMP),   BK(128, BM_NWG, SC_CMP),  BK(152, BM_NWG, SC_CMP),
+#define AK(R, M, S, SH) {R, M, S, nullptr, "batch_affine_kernel<R=" #R "," #M "," #S ">", batch_affine_kernel<R, S, SH>}
+    AK(32, BM_AFFS, SC_PERM, true),  AK(52, BM_AFFS, SC_PERM, true),  AK(32, BM_AFFS, SC_CMP, true),  AK(52, BM_AFFS, SC_CMP, true),
+    AK(32, BM_AFF, SC_PERM, false),  AK(52, BM_AFF, SC_PERM, false),  AK(32, BM_AFF, SC_CMP, false),  AK(52, BM_AFF, SC_CMP, false),
+#undef AK
 };
 #undef BK
 
@@ -229,6 +238,8 @@ struct pwa_batch {
     bool use_strips = false;
     const BatchKernelEntry* kern = nullptr;
     BatchParams bp{};
+    bool affine = false;
+    int32_t aff_go = 0, aff_ge = 0, aff_neg = 0;
     uint32_t grid = 0;
     DevBuf arena, tasks, slot_poff, slot_plen, slot_out, hand, queue, scores;
     // engine 2: wavefront kernels without traceback band (exact end cells, any scoring)
@@ -301,11 +312,13 @@ void pwa_ctx_destroy(pwa_ctx* c) {
 const char* pwa_last_error(const pwa_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 // ---------------------------------------------------------------------------- batch: create
-int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* seq_bytes,
-                     const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
-                     uint64_t n_pairs, int want_end_cells, pwa_batch** out) {
+} // extern "C" (reopened below): the shared implementation has C++ linkage
+static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, bool affine, int gap_extend,
+                             const uint8_t* seq_bytes, const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a,
+                             const uint32_t* pair_b, uint64_t n_pairs, int want_end_cells, pwa_batch** out) {
     if (!ctx || !out) return PWA_E_INVALID;
     *out = nullptr;
+    if (affine && want_end_cells) return fail(ctx, PWA_E_INVALID, "end cells are not defined for the affine score pass");
     if (mode != PWA_MODE_NW && mode != PWA_MODE_SW) return fail(ctx, PWA_E_INVALID, "unknown mode");
     if (!seq_off || (n_pairs && (!pair_a || !pair_b))) return fail(ctx, PWA_E_INVALID, "null input");
     if (n_seq && !seq_bytes && seq_off[n_seq] != 0) return fail(ctx, PWA_E_INVALID, "null seq_bytes");
@@ -343,7 +356,9 @@ int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, c
         const uint64_t n = slen(pair_a[k]), m = slen(pair_b[k]);
         if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
         if (n == 0 || m == 0) {
-            if (!local) b->host_scores[k] = wrap_mul((int64_t)(n + m), gap);   // dp[n][0] / dp[0][m], hw2.cpp:125-136
+            if (affine) {   // hw3.cpp:39-52: V[0][0] = 0, F[n][0] = Go + Ge(n-1), E[0][m] = Go + Ge(m-1)
+                b->host_scores[k] = (n + m == 0) ? 0 : (int32_t)((uint32_t)gap + (uint32_t)wrap_mul((int64_t)(n + m - 1), gap_extend));
+            } else if (!local) b->host_scores[k] = wrap_mul((int64_t)(n + m), gap);   // dp[n][0] / dp[0][m], hw2.cpp:125-136
             if (b->want_end && !local) {
                 b->host_end_i[k] = (uint32_t)n;
                 b->host_end_j[k] = (uint32_t)m;
@@ -394,7 +409,8 @@ int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, c
 
     // ---- engine choice.  The strip engine pads short patterns with rows that match nothing; for SW
     // those rows can only hold values <= real rows if mismatch <= 0 and gap <= 0.
-    const bool strips_ok = !b->want_end && (!local || (mismatch <= 0 && gap <= 0));
+    const bool strips_ok = affine || (!b->want_end && (!local || (mismatch <= 0 && gap <= 0)));
+    b->affine = affine;
     auto fits8 = [](int v) { return v >= -128 && v <= 127; };
     b->use_strips = strips_ok;
 
@@ -402,7 +418,23 @@ int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, c
     int score_path = SC_CMP;
     int kmode = local ? BM_SW : BM_NW;
     int tab_match = match, tab_mismatch = mismatch;
-    if (b->use_strips) {
+    if (affine) {
+        // Ge(i+j)-shifted form when every value stays far inside int32 (the sentinels are -2^29 there)
+        const int64_t amax = std::max<int64_t>({std::llabs((long long)match), std::llabs((long long)mismatch),
+                                                std::llabs((long long)gap), std::llabs((long long)gap_extend)});
+        const bool shift_ok = (int64_t)(max_n + max_m + 4) * amax * 4 < (1ll << 27);
+        kmode = shift_ok ? BM_AFFS : BM_AFF;
+        b->aff_go = gap;
+        b->aff_ge = gap_extend;
+        b->aff_neg = shift_ok ? -(1 << 29) : std::numeric_limits<int32_t>::min() / 2;   // hw3.cpp:16
+        if (shift_ok) {
+            tab_match = match - 2 * gap_extend;
+            tab_mismatch = mismatch - 2 * gap_extend;
+        }
+        if (n_alpha <= 7 && fits8(tab_match) && fits8(tab_mismatch)) score_path = SC_PERM;
+        if (score_path == SC_CMP && absent_byte < 0)
+            return fail(ctx, PWA_E_INVALID, "affine pass: the texts use all 256 byte values, no padding symbol left");
+    } else if (b->use_strips) {
         if (!local) {
             // gap-shifted NW: G = H - g(i+j) needs every |value| to stay far inside int32
             const int64_t amax = std::max<int64_t>({std::llabs((long long)match), std::llabs((long long)mismatch),
@@ -486,6 +518,7 @@ int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, c
         b->kern = find_batch_kernel(R, kmode, score_path);
         if (!b->kern) return fail(ctx, PWA_E_INVALID, "internal: no kernel instantiation");
         b->kernel_name = b->kern->name;
+        const void* kfn = affine ? reinterpret_cast<const void*>(b->kern->afn) : reinterpret_cast<const void*>(b->kern->fn);
 
         std::sort(ht.begin(), ht.end(), [&](const HostTask& x, const HostTask& y) {   // longest first
             const uint64_t cx = (x.maxlen + R - 1) / R * slen(x.text), cy = (y.maxlen + R - 1) / R * slen(y.text);
@@ -519,10 +552,11 @@ int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, c
         HIPC(ctx, hipMemcpy(b->slot_out.p, sout.data(), nt * 64 * 4, hipMemcpyHostToDevice));
 
         int per_cu = 0;
-        HIPC(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(b->kern->fn), 64, 0));
+        HIPC(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64, 0));
         per_cu = std::max(1, std::min(per_cu, 32));
         b->grid = (uint32_t)std::min<uint64_t>(nt, (uint64_t)ctx->num_cu * per_cu);
-        const uint64_t half = (max_strips > 1) ? ((max_m + 3) / 4 + 1) * 256 : 256;   // int32 per half
+        // int32 per half: one (affine: two) int4 per lane per 4-column block
+        const uint64_t half = ((max_strips > 1) ? ((max_m + 3) / 4 + 1) * 256 : 256) * (affine ? 2 : 1);
         HIPC(ctx, b->hand.alloc((size_t)b->grid * 2 * half * sizeof(int32_t)));
 
         BatchParams& P = b->bp;
@@ -578,6 +612,36 @@ int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, c
     return PWA_OK;
 }
 
+extern "C" {
+
+int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* seq_bytes,
+                     const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
+                     uint64_t n_pairs, int want_end_cells, pwa_batch** out) {
+    return batch_create_impl(ctx, mode, match, mismatch, gap, false, 0, seq_bytes, seq_off, n_seq, pair_a, pair_b, n_pairs,
+                             want_end_cells, out);
+}
+
+int pwa_affine_batch_create(pwa_ctx* ctx, int match, int mismatch, int gap_open, int gap_extend, const uint8_t* seq_bytes,
+                            const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
+                            uint64_t n_pairs, pwa_batch** out) {
+    return batch_create_impl(ctx, PWA_MODE_NW, match, mismatch, gap_open, true, gap_extend, seq_bytes, seq_off, n_seq, pair_a,
+                             pair_b, n_pairs, 0, out);
+}
+
+int pwa_scores_affine(pwa_ctx* ctx, int match, int mismatch, int gap_open, int gap_extend, const uint8_t* seq_bytes,
+                      const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b, uint64_t n_pairs,
+                      int32_t* score_out) {
+    if (!ctx || !score_out) return PWA_E_INVALID;
+    pwa_batch* b = nullptr;
+    int rc = pwa_affine_batch_create(ctx, match, mismatch, gap_open, gap_extend, seq_bytes, seq_off, n_seq, pair_a, pair_b,
+                                     n_pairs, &b);
+    if (rc != PWA_OK) return rc;
+    rc = pwa_batch_run(b, nullptr);
+    if (rc == PWA_OK) rc = pwa_batch_fetch(b, score_out, nullptr, nullptr);
+    pwa_batch_destroy(b);
+    return rc;
+}
+
 int pwa_batch_run(pwa_batch* b, void* stream_v) {
     if (!b) return PWA_E_INVALID;
     pwa_ctx* ctx = b->ctx;
@@ -587,7 +651,16 @@ int pwa_batch_run(pwa_batch* b, void* stream_v) {
     if (b->n_live) {
         if (b->use_strips) {
             HIPC(ctx, hipMemsetAsync(b->queue.p, 0, 16, st));
-            hipLaunchKernelGGL(b->kern->fn, dim3(b->grid), dim3(64), 0, st, b->bp);
+            if (b->affine) {
+                AffineParams ap;
+                ap.b = b->bp;
+                ap.go = b->aff_go;
+                ap.ge = b->aff_ge;
+                ap.neg = b->aff_neg;
+                hipLaunchKernelGGL(b->kern->afn, dim3(b->grid), dim3(64), 0, st, ap);
+            } else {
+                hipLaunchKernelGGL(b->kern->fn, dim3(b->grid), dim3(64), 0, st, b->bp);
+            }
             HIPC(ctx, hipGetLastError());
         } else {
             const int rc = b->pl.launch(ctx, st, b->mode == PWA_MODE_SW, false, false, nullptr);

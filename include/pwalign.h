@@ -101,6 +101,24 @@ int pwa_batch_run_times(pwa_batch *b, float *ms_out, int cap, int *n_out);
 void pwa_batch_destroy(pwa_batch *b);
 
 /*
+ * Affine-gap global alignment SCORES of many pairs -- the score pass of the sibling program
+ *   /root/reference/Multiple_Sequence_Alignment/hw3.cpp
+ * i.e. `affine_alignment(Si, Sj, M, Mm, Go, Ge, &score)` (hw3.cpp:23-102) as called by the all-pairs
+ * loop of the center-star MSA (hw3.cpp:232-241).  The recurrence is hw3's own three-matrix form with
+ * its quirks (boundary gap of length L costs Go + Ge(L-1), interior gap Go + Ge*L; F never reads E and
+ * E never reads F; result = max(V, F, E)[n][m]); it is NOT interchangeable with hw2's linear-gap NW.
+ * pair (a, b): string1 = sequence a (rows), string2 = sequence b (columns).
+ * The returned batch object works with pwa_batch_run / _d_scores / _set_d_scores / _fetch / _info /
+ * _run_times / _destroy exactly like a linear-gap batch (no end cells).
+ */
+int pwa_affine_batch_create(pwa_ctx *ctx, int match, int mismatch, int gap_open, int gap_extend, const uint8_t *seq_bytes,
+                            const uint64_t *seq_off, uint32_t n_seq, const uint32_t *pair_a, const uint32_t *pair_b,
+                            uint64_t n_pairs, pwa_batch **out);
+int pwa_scores_affine(pwa_ctx *ctx, int match, int mismatch, int gap_open, int gap_extend, const uint8_t *seq_bytes,
+                      const uint64_t *seq_off, uint32_t n_seq, const uint32_t *pair_a, const uint32_t *pair_b,
+                      uint64_t n_pairs, int32_t *score_out);
+
+/*
  * Full alignment of ONE pair: matrix fill with the traceback band in HBM + traceback walk on
  * the device.  Replaces one call of hw2.cpp:118 / hw2.cpp:192 up to (not including) the string
  * post-processing prepareCigarString / prepareMDZString (59-116), which stays on the host.
