@@ -182,7 +182,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c2", "c5", "hw3"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c2", "c2b", "c5", "hw3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced sizes (functional check only; line is marked invalid)")
     args = ap.parse_args()
@@ -207,7 +207,7 @@ def main():
     pkg = load_pkg()
     ctx = pkg.Context(local_rank)
 
-    if args.workload in ("c2", "c5"):
+    if args.workload in ("c2", "c2b", "c5"):
         return bench_single_pair(args, pkg, ctx, rank, world, dist if use_dist else None, torch)
 
     if args.workload == "c3":
@@ -368,9 +368,12 @@ def main():
 
 def bench_single_pair(args, pkg, ctx, rank, world, dist, torch):
     """c2 / c5: one big pair, full fill + traceback band in HBM.  Does not shard: replicas only."""
-    if args.workload == "c2":
+    if args.workload in ("c2", "c2b"):
         n = m = 2000 if args.small else 10000
         mode, label = "sw", "c2: SW 1 pair %dx%d, traceback band in HBM" % (n, m)
+        if args.workload == "c2b":   # SURVEY.md 8(d) row C2 accounting: 4 B int32 score band + 1 B traceback band
+            ctx.set_score_band(True)
+            label = "c2b: SW 1 pair %dx%d, int32 score band + traceback band in HBM (5 B/cell)" % (n, m)
     else:
         n = m = 5000 if args.small else 100000
         mode, label = "nw", "c5: NW 1 pair %dx%d, traceback band in HBM" % (n, m)

@@ -23,7 +23,7 @@ CLI_PATH = os.path.join(_HERE, "host", "hw2_amd")
 MODE = {"nw": 0, "sw": 1, "global": 0, "local": 1}
 
 EXPORTS = [
-    "pwa_version", "pwa_strerror", "pwa_ctx_create", "pwa_ctx_destroy", "pwa_last_error", "pwa_scores",
+    "pwa_version", "pwa_strerror", "pwa_ctx_create", "pwa_ctx_destroy", "pwa_last_error", "pwa_ctx_set_score_band", "pwa_scores",
     "pwa_batch_create", "pwa_affine_batch_create", "pwa_scores_affine", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_set_d_scores", "pwa_batch_fetch", "pwa_batch_info",
     "pwa_batch_last_ms", "pwa_batch_run_times", "pwa_batch_destroy", "pwa_align", "pwa_align_matrices", "pwa_align_last_stats", "pwa_align_batch",
     "pwa_cigar_bound", "pwa_mdz_bound", "pwa_format_alignment",
@@ -55,6 +55,7 @@ def lib():
     L.pwa_ctx_destroy.restype = None
     L.pwa_last_error.argtypes = [vp]
     L.pwa_last_error.restype = C.c_char_p
+    L.pwa_ctx_set_score_band.argtypes = [vp, C.c_int]
     batch_in = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, u64p, C.c_uint32, u32p, u32p, C.c_uint64]
     L.pwa_scores.argtypes = batch_in + [i32p, u32p, u32p]
     L.pwa_batch_create.argtypes = batch_in + [C.c_int, C.POINTER(vp)]
@@ -143,6 +144,9 @@ class Context:
 
     def __exit__(self, *a):
         self.close()
+
+    def set_score_band(self, on):
+        self._check(self._L.pwa_ctx_set_score_band(self._h, 1 if on else 0), "pwa_ctx_set_score_band")
 
     def _check(self, rc, what):
         if rc != 0:

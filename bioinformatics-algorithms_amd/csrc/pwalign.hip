@@ -29,6 +29,7 @@ struct pwa_ctx {
     std::string err;
     float fill_ms = 0.f, tb_ms = 0.f;
     uint64_t band_bytes = 0;
+    bool score_band = false;   // pwa_ctx_set_score_band: also materialise the int32 score band in HBM
 };
 
 namespace {
@@ -310,6 +311,12 @@ void pwa_ctx_destroy(pwa_ctx* c) {
 }
 
 const char* pwa_last_error(const pwa_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int pwa_ctx_set_score_band(pwa_ctx* c, int on) {
+    if (!c) return PWA_E_INVALID;
+    c->score_band = on != 0;
+    return PWA_OK;
+}
 
 // ---------------------------------------------------------------------------- batch: create
 } // extern "C" (reopened below): the shared implementation has C++ linkage
@@ -833,7 +840,7 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
             const uint64_t n = slen(pair_a[k1]), m = slen(pair_b[k1]);
             if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
             const uint64_t need = (n && m) ? align_up(tb_band_bytes(n, m), 256) : 0;
-            if (k1 > k0 && band + need + opsb + n + m > budget) break;
+            if (k1 > k0 && (band + need) * (ctx->score_band ? 5 : 1) + opsb + n + m > budget) break;
             band += need;
             opsb += align_up(n + m + 1, 16);
             max_m = std::max(max_m, m);
@@ -842,9 +849,10 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
         const uint64_t nc = k1 - k0;
         if (band + opsb > budget && nc == 1 && band + opsb > (uint64_t)(free_b * 0.97))
             return fail(ctx, PWA_E_NOMEM, "traceback band of a single pair exceeds free HBM");
-        DevBuf d_band, d_ops, d_res;
+        DevBuf d_band, d_sband, d_ops, d_res;
         PairLaunch pl;
         HIPC(ctx, d_band.alloc(band + 32768));   // + one traceback window: the walk stages whole windows
+        if (ctx->score_band) HIPC(ctx, d_sband.alloc(band * sizeof(int32_t)));
         HIPC(ctx, d_ops.alloc(opsb));
         HIPC(ctx, d_res.alloc(nc * sizeof(PairResult)));
         std::vector<PairResult> res(nc);
@@ -863,12 +871,13 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
                 d.n = (int32_t)n;
                 d.m = (int32_t)m;
                 d.tb = d_band.as<uint8_t>() + bo;
+                if (ctx->score_band) d.sband = d_sband.as<int32_t>() + bo;
                 d.res = d_res.as<PairResult>() + q;
                 d.ops = d_ops.as<uint8_t>() + oo;
                 d.ops_cap = (uint32_t)std::min<uint64_t>(n + m, 0xffffffffu);
                 pd.push_back(d);
                 bo += align_up(tb_band_bytes(n, m), 256);
-                ctx->band_bytes += tb_band_bytes(n, m);
+                ctx->band_bytes += tb_band_bytes(n, m) * (ctx->score_band ? 5 : 1);
             } else if (!local) {
                 res[q].score = wrap_mul((int64_t)(n + m), gap);
                 res[q].end_i = (uint32_t)n;
@@ -884,7 +893,7 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
             if (dbg) std::fprintf(stderr, "[pwa] fill launch grid=%u pairs=%u tasks=%u band=%llu rows=%llu\n", pl.grid,
                                   pl.G.n_pairs, pl.G.n_tasks, (unsigned long long)band, (unsigned long long)pl.row_bytes);
             HIPC(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-            rc = pl.launch(ctx, ctx->stream, local, true, true, ctx->ev[1]);
+            rc = pl.launch(ctx, ctx->stream, local, true, true, ctx->ev[1], ctx->score_band);
             if (rc != PWA_OK) return rc;
             HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
             HIPC(ctx, hipStreamSynchronize(ctx->stream));

@@ -51,6 +51,11 @@ const char *pwa_strerror(int code);
 int pwa_ctx_create(int device, pwa_ctx **out);
 void pwa_ctx_destroy(pwa_ctx *ctx);
 const char *pwa_last_error(const pwa_ctx *ctx);
+/* When on, pwa_align / pwa_align_batch also materialise the int32 SCORE band in HBM next to the
+ * traceback band (4 + 1 B/cell: the reference's own footprint, hw2.cpp:119-120 / 193-194), written as
+ * one coalesced 64*RL*4-byte wave store per anti-diagonal step.  The walk does not need it; it exists
+ * for inspection (pwa_align_matrices returns it) and for the 5 B/cell roofline accounting. */
+int pwa_ctx_set_score_band(pwa_ctx *ctx, int on);
 
 /*
  * Scores of many pairs (the scores-only pass over hw2.cpp's pair loop 328-338; for -l the
