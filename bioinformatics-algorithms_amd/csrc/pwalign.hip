@@ -322,7 +322,7 @@ int pwa_ctx_set_score_band(pwa_ctx* c, int on) {
 } // extern "C" (reopened below): the shared implementation has C++ linkage
 static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, bool affine, int gap_extend,
                              const uint8_t* seq_bytes, const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a,
-                             const uint32_t* pair_b, uint64_t n_pairs, int want_end_cells, pwa_batch** out) {
+                             const uint32_t* pair_b, uint64_t n_pairs, int want_end_cells, pwa_batch** out) try {
     if (!ctx || !out) return PWA_E_INVALID;
     *out = nullptr;
     if (affine && want_end_cells) return fail(ctx, PWA_E_INVALID, "end cells are not defined for the affine score pass");
@@ -617,6 +617,10 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
     guard.b = nullptr;
     *out = b;
     return PWA_OK;
+} catch (const std::bad_alloc&) {
+    return fail(ctx, PWA_E_NOMEM, "host allocation failed");
+} catch (...) {
+    return fail(ctx, PWA_E_HIP, "unexpected C++ exception");   // nothing may propagate across the C ABI
 }
 
 extern "C" {
@@ -728,7 +732,7 @@ int pwa_batch_info(const pwa_batch* b, uint64_t* cells, uint64_t* padded_cells, 
     return PWA_OK;
 }
 
-int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint32_t* end_j_out) {
+int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint32_t* end_j_out) try {
     if (!b || !score_out) return PWA_E_INVALID;
     pwa_ctx* ctx = b->ctx;
     if ((end_i_out || end_j_out) && !b->want_end) return fail(ctx, PWA_E_INVALID, "batch was created without end cells");
@@ -760,6 +764,10 @@ int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint3
         if (end_j_out) end_j_out[k] = res[q].end_j;
     }
     return PWA_OK;
+} catch (const std::bad_alloc&) {
+    return fail(b ? b->ctx : nullptr, PWA_E_NOMEM, "host allocation failed");
+} catch (...) {
+    return fail(b ? b->ctx : nullptr, PWA_E_HIP, "unexpected C++ exception");   // nothing may propagate across the C ABI
 }
 
 void pwa_batch_destroy(pwa_batch* b) {
@@ -790,7 +798,7 @@ int pwa_scores(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const u
 int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* seq_bytes,
                     const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
                     uint64_t n_pairs, int32_t* score_out, uint8_t* ops, const uint64_t* ops_off, uint64_t* n_ops,
-                    uint64_t* end_cells, uint64_t* start_cells) {
+                    uint64_t* end_cells, uint64_t* start_cells) try {
     if (!ctx) return PWA_E_INVALID;
     if (mode != PWA_MODE_NW && mode != PWA_MODE_SW) return fail(ctx, PWA_E_INVALID, "unknown mode");
     if (!seq_off || !score_out || !ops_off || !n_ops || (n_pairs && (!pair_a || !pair_b)))
@@ -935,11 +943,15 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
         k0 = k1;
     }
     return PWA_OK;
+} catch (const std::bad_alloc&) {
+    return fail(ctx, PWA_E_NOMEM, "host allocation failed");
+} catch (...) {
+    return fail(ctx, PWA_E_HIP, "unexpected C++ exception");   // nothing may propagate across the C ABI
 }
 
 int pwa_align(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* pattern, uint64_t n,
               const uint8_t* text, uint64_t m, int32_t* score, uint8_t* ops, uint64_t ops_cap, uint64_t* n_ops,
-              uint64_t end_cell[2], uint64_t start_cell[2]) {
+              uint64_t end_cell[2], uint64_t start_cell[2]) try {
     if (!ctx) return PWA_E_INVALID;
     if (!score || !ops || !n_ops || (n && !pattern) || (m && !text)) return fail(ctx, PWA_E_INVALID, "null input");
     if (ops_cap < n + m) return fail(ctx, PWA_E_CAPACITY, "ops_cap must be at least n + m");
@@ -951,10 +963,14 @@ int pwa_align(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const ui
     const uint64_t ooff = 0;
     return pwa_align_batch(ctx, mode, match, mismatch, gap, bytes.data(), off, 2, &a, &b, 1, score, ops, &ooff, n_ops,
                            end_cell, start_cell);
+} catch (const std::bad_alloc&) {
+    return fail(ctx, PWA_E_NOMEM, "host allocation failed");
+} catch (...) {
+    return fail(ctx, PWA_E_HIP, "unexpected C++ exception");   // nothing may propagate across the C ABI
 }
 
 int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* pattern, uint64_t n,
-                       const uint8_t* text, uint64_t m, int32_t* dp_out, char* tb_out) {
+                       const uint8_t* text, uint64_t m, int32_t* dp_out, char* tb_out) try {
     if (!ctx) return PWA_E_INVALID;
     if (mode != PWA_MODE_NW && mode != PWA_MODE_SW) return fail(ctx, PWA_E_INVALID, "unknown mode");
     if ((n && !pattern) || (m && !text) || (!dp_out && !tb_out)) return fail(ctx, PWA_E_INVALID, "null input");
@@ -1016,6 +1032,10 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
         }
     }
     return PWA_OK;
+} catch (const std::bad_alloc&) {
+    return fail(ctx, PWA_E_NOMEM, "host allocation failed");
+} catch (...) {
+    return fail(ctx, PWA_E_HIP, "unexpected C++ exception");   // nothing may propagate across the C ABI
 }
 
 int pwa_align_last_stats(const pwa_ctx* ctx, float* fill_ms, float* traceback_ms, uint64_t* band_bytes) {
