@@ -512,8 +512,13 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             if (e.mode != kmode || e.score != score_path) continue;
             const int R = e.R;
             if (force && std::atoi(force) != R) continue;
+            // evaluated cells + the strip hand-off priced at ~2 cells per column and strip boundary ([gpu]: the
+            // 1000-row affine pass is equally fast at R = 32 and 52 but moves 37 % fewer HBM bytes at 52)
             long double cost = 0;
-            for (const auto& t : ht) cost += (long double)((t.maxlen + R - 1) / R * R) * (long double)slen(t.text) * 64.0L;
+            for (const auto& t : ht) {
+                const uint64_t strips = (t.maxlen + R - 1) / R;
+                cost += (long double)(strips * R + 2 * (strips - 1)) * (long double)slen(t.text) * 64.0L;
+            }
             if (best_cost < 0 || cost < best_cost || (cost == best_cost && R > bestR)) {
                 best_cost = cost;
                 bestR = R;
@@ -521,7 +526,8 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         }
         if (bestR == 0) return fail(ctx, PWA_E_INVALID, "internal: no kernel instantiation");
         const int R = bestR;
-        b->padded_cells = (uint64_t)best_cost;
+        b->padded_cells = 0;
+        for (const auto& t : ht) b->padded_cells += (t.maxlen + bestR - 1) / bestR * bestR * slen(t.text) * 64;
         b->kern = find_batch_kernel(R, kmode, score_path);
         if (!b->kern) return fail(ctx, PWA_E_INVALID, "internal: no kernel instantiation");
         b->kernel_name = b->kern->name;
