@@ -230,8 +230,9 @@ class Context:
                                      ooff, nops, endc, startc)
         self._check(rc, "pwa_align_batch")
         res = []
+        raw = memoryview(ops)   # no per-pair copy of the whole buffer
         for k in range(n):
-            o = ops.raw[ooff[k]:ooff[k] + nops[k]]
+            o = bytes(raw[ooff[k]:ooff[k] + nops[k]])
             res.append(dict(score=sc[k], ops=o, end=(endc[2 * k], endc[2 * k + 1]),
                             start=(startc[2 * k], startc[2 * k + 1])))
         return res
