@@ -14,6 +14,10 @@ ORACLE_CLI = os.path.join(ORACLE_DIR, "hw2_oracle_cli")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libhw2_ref.so")
 REF_CLI = os.path.join(ORACLE_DIR, "_ref", "hw2_ref")
 ORACLE3_SO = os.path.join(ORACLE_DIR, "liboracle_hw3.so")
+ORACLE4_SO = os.path.join(ORACLE_DIR, "liboracle_hw4.so")
+ORACLE4_CLI = os.path.join(ORACLE_DIR, "hw4_oracle_cli")
+REF4_SO = os.path.join(ORACLE_DIR, "_ref", "libhw4_ref.so")
+REF4_CLI = os.path.join(ORACLE_DIR, "_ref", "hw4_ref")
 REF3_SO = os.path.join(ORACLE_DIR, "_ref", "libhw3_ref.so")
 REF3_CLI = os.path.join(ORACLE_DIR, "_ref", "hw3_ref")
 
@@ -259,3 +263,53 @@ def read_fasta_hw3(path):
     if header:
         recs.append((header, seq))
     return recs
+
+
+# ---------------------------------------------------------------------------- hw4 NW distance / UPGMA
+_lib4 = None
+_ref4 = None
+
+
+def oracle4():
+    global _lib4
+    if _lib4 is None:
+        if not os.path.exists(ORACLE4_SO):
+            build_oracle(with_ref=False)
+        lib = C.CDLL(ORACLE4_SO)
+        lib.orc4_nw_distance.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]
+        lib.orc4_nw_distance.restype = C.c_int32
+        lib.orc4_upgma.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_char_p), C.c_size_t]
+        lib.orc4_upgma.restype = C.c_void_p
+        _lib4 = lib
+    return _lib4
+
+
+def have_ref4():
+    return os.path.exists(REF4_SO)
+
+
+def nw_distance(s1, s2, match, mismatch, gap):
+    """Oracle: (distance, score) of hw4.cpp's needleman_wunsch + distance rule (16-72, 146-152)."""
+    s1, s2 = _as_bytes(s1), _as_bytes(s2)
+    sc = C.c_int32(0)
+    d = oracle4().orc4_nw_distance(s1, len(s1), s2, len(s2), match, mismatch, gap, C.byref(sc))
+    return d, sc.value
+
+
+def ref_nw_distance(s1, s2, match, mismatch, gap):
+    global _ref4
+    if _ref4 is None:
+        _ref4 = C.CDLL(REF4_SO)
+        _ref4.ref4_nw_distance.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+        _ref4.ref4_nw_distance.restype = C.c_int
+    s1, s2 = _as_bytes(s1), _as_bytes(s2)
+    return _ref4.ref4_nw_distance(s1, len(s1), s2, len(s2), match, mismatch, gap)
+
+
+def upgma(dist_rows, names):
+    """Oracle UPGMA (hw4.cpp:162-228): dense symmetric matrix -> Newick bytes."""
+    n = len(names)
+    flat = (C.c_double * max(n * n, 1))(*[x for row in dist_rows for x in row])
+    arr = (C.c_char_p * max(n, 1))(*[_as_bytes(x) for x in names])
+    p = oracle4().orc4_upgma(flat, arr, n)
+    return C.string_at(p)
