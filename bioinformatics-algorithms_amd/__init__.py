@@ -19,12 +19,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpwalign.so")
 CLI_PATH = os.path.join(_HERE, "host", "hw2_amd")
+CLI4_PATH = os.path.join(_HERE, "host", "hw4_amd")
 
 MODE = {"nw": 0, "sw": 1, "global": 0, "local": 1}
 
 EXPORTS = [
     "pwa_version", "pwa_strerror", "pwa_ctx_create", "pwa_ctx_destroy", "pwa_last_error", "pwa_ctx_set_score_band", "pwa_scores",
-    "pwa_batch_create", "pwa_affine_batch_create", "pwa_scores_affine", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_set_d_scores", "pwa_batch_fetch", "pwa_batch_info",
+    "pwa_batch_create", "pwa_affine_batch_create", "pwa_scores_affine", "pwa_nwdist_batch_create", "pwa_distances", "pwa_upgma_newick", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_set_d_scores", "pwa_batch_fetch", "pwa_batch_info",
     "pwa_batch_last_ms", "pwa_batch_run_times", "pwa_batch_destroy", "pwa_align", "pwa_align_matrices", "pwa_align_last_stats", "pwa_align_batch",
     "pwa_cigar_bound", "pwa_mdz_bound", "pwa_format_alignment",
 ]
@@ -62,6 +63,9 @@ def lib():
     affine_in = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, u64p, C.c_uint32, u32p, u32p, C.c_uint64]
     L.pwa_affine_batch_create.argtypes = affine_in + [C.POINTER(vp)]
     L.pwa_scores_affine.argtypes = affine_in + [i32p]
+    L.pwa_nwdist_batch_create.argtypes = batch_in[:1] + batch_in[2:] + [C.POINTER(vp)]
+    L.pwa_distances.argtypes = batch_in[:1] + batch_in[2:] + [i32p]
+    L.pwa_upgma_newick.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_char_p), C.c_uint32, vp, C.c_uint64, u64p]
     L.pwa_batch_run.argtypes = [vp, vp]
     L.pwa_batch_d_scores.argtypes = [vp]
     L.pwa_batch_d_scores.restype = vp
@@ -118,6 +122,21 @@ def format_alignment(pattern, text, ops, end):
         raise PwaError("pwa_format_alignment: %s" % L.pwa_strerror(rc).decode())
     return dict(aligned_pattern=ap.raw[:n_ops], aligned_reference=ar.raw[:n_ops], cigar=cg.value, mdz=md.value,
                 overlap=ov.value)
+
+
+def upgma_newick(dist_rows, names):
+    """Host UPGMA + Newick (hw4.cpp:162-228) through the C ABI."""
+    L = lib()
+    n = len(names)
+    flat = (C.c_double * max(n * n, 1))(*[float(x) for row in dist_rows for x in row])
+    arr = (C.c_char_p * max(n, 1))(*[_b(x) for x in names])
+    need = C.c_uint64(0)
+    L.pwa_upgma_newick(flat, arr, n, None, 0, C.byref(need))
+    buf = C.create_string_buffer(need.value + 1)
+    rc = L.pwa_upgma_newick(flat, arr, n, buf, need.value + 1, C.byref(need))
+    if rc != 0:
+        raise PwaError("pwa_upgma_newick: %s" % L.pwa_strerror(rc).decode())
+    return buf.value
 
 
 class Context:
@@ -178,6 +197,17 @@ class Context:
         out = b.fetch()
         b.close()
         return out
+
+    # -- hw4.cpp all-pairs step: NW (tie-break diag >= up >= left) + gap/mismatch column count (16-72, 146-152)
+    def distances(self, seqs, pair_a, pair_b, match, mismatch, gap):
+        b = Batch(self, "nwdist", seqs, pair_a, pair_b, match, mismatch, gap)
+        b.run()
+        out = b.fetch()
+        b.close()
+        return out
+
+    def batch_distances(self, seqs, pair_a, pair_b, match, mismatch, gap):
+        return Batch(self, "nwdist", seqs, pair_a, pair_b, match, mismatch, gap)
 
     def batch_affine(self, seqs, pair_a, pair_b, match, mismatch, gap_open, gap_extend):
         return Batch(self, "affine", seqs, pair_a, pair_b, match, mismatch, gap_open, gap_extend=gap_extend)
@@ -259,7 +289,9 @@ class Batch:
             pa = (C.c_uint32 * max(n, 1))(*pair_a)
             pb = (C.c_uint32 * max(n, 1))(*pair_b)
         h = C.c_void_p()
-        if mode == "affine":
+        if mode == "nwdist":
+            rc = self._L.pwa_nwdist_batch_create(ctx._h, match, mismatch, gap, blob, off, len(seqs), pa, pb, n, C.byref(h))
+        elif mode == "affine":
             rc = self._L.pwa_affine_batch_create(ctx._h, match, mismatch, gap, gap_extend, blob, off, len(seqs), pa, pb, n,
                                                  C.byref(h))
         else:

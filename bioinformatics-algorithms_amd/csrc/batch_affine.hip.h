@@ -186,8 +186,8 @@ __global__ __launch_bounds__(64, affine_waves_per_simd(R)) void batch_affine_ker
                     f0 = f1; f1 = f2;
                     int dbot1[1], fbot1[1];
                     affine_block<R, 1, SCORE, SHIFT>(Vg, E, D, pk, cs1, dtop1, fin1, topprev, dbot1, fbot1, P);
-                    hout[((size_t)nblk * 2 * out_stride / 2 + lane) * 4 + k] = dbot1[0];
-                    hout[((size_t)nblk * 2 * out_stride / 2 + 64 + lane) * 4 + k] = fbot1[0];
+                    hout[((size_t)nblk * out_stride + lane) * 4 + k] = dbot1[0];
+                    hout[((size_t)nblk * out_stride + 64 + lane) * 4 + k] = fbot1[0];
                 }
             }
             // ---- max(V, F, E)[n][m] sits in this strip for the lanes whose pattern ends here (hw3.cpp:88-97)

@@ -16,6 +16,7 @@
 
 #include "batch_scores.hip.h"
 #include "batch_affine.hip.h"
+#include "batch_nwdist.hip.h"
 #include "pair_fill.hip.h"
 
 using namespace pwa;
@@ -78,12 +79,14 @@ inline int32_t wrap_mul(int64_t a, int32_t b) { return (int32_t)((uint32_t)a * (
 // --------------------------------------------------------------------------- kernel tables
 typedef void (*batch_kernel_t)(const BatchParams);
 typedef void (*affine_kernel_t)(const AffineParams);
-enum { BM_AFF = 3, BM_AFFS = 4 };   // affine (hw3) plain / Ge(i+j)-shifted; modes 0..2 are in batch_scores.hip.h
+typedef void (*nwdist_kernel_t)(const NwDistParams);
+enum { BM_AFF = 3, BM_AFFS = 4, BM_DIST = 5 };   // affine (hw3) plain / shifted, hw4 NW + distance; 0..2: batch_scores.hip.h
 struct BatchKernelEntry {
     int R, mode, score;
     batch_kernel_t fn;
     const char* name;
     affine_kernel_t afn = nullptr;
+    nwdist_kernel_t dfn = nullptr;
 };
 #define BK(R, M, S) {R, M, S, batch_scores_kernel<R, M, S>, "batch_scores_kernel<R=" #R "," #M "," #S ">"}
 const BatchKernelEntry kBatchKernels[] = {
@@ -98,6 +101,9 @@ const BatchKernelEntry kBatchKernels[] = {
     AK(32, BM_AFFS, SC_PERM, true),  AK(52, BM_AFFS, SC_PERM, true),  AK(32, BM_AFFS, SC_CMP, true),  AK(52, BM_AFFS, SC_CMP, true),
     AK(32, BM_AFF, SC_PERM, false),  AK(52, BM_AFF, SC_PERM, false),  AK(32, BM_AFF, SC_CMP, false),  AK(52, BM_AFF, SC_CMP, false),
 #undef AK
+#define DK(R, S) {R, BM_DIST, S, nullptr, "batch_nwdist_kernel<R=" #R "," #S ">", nullptr, batch_nwdist_kernel<R, S>}
+    DK(32, SC_PERM), DK(64, SC_PERM), DK(32, SC_CMP), DK(64, SC_CMP),
+#undef DK
 };
 #undef BK
 
@@ -239,7 +245,7 @@ struct pwa_batch {
     bool use_strips = false;
     const BatchKernelEntry* kern = nullptr;
     BatchParams bp{};
-    bool affine = false;
+    bool affine = false, nwdist = false;
     int32_t aff_go = 0, aff_ge = 0, aff_neg = 0;
     uint32_t grid = 0;
     DevBuf arena, tasks, slot_poff, slot_plen, slot_out, hand, queue, scores;
@@ -320,12 +326,14 @@ int pwa_ctx_set_score_band(pwa_ctx* c, int on) {
 
 // ---------------------------------------------------------------------------- batch: create
 } // extern "C" (reopened below): the shared implementation has C++ linkage
-static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, bool affine, int gap_extend,
+enum { KIND_LINEAR = 0, KIND_AFFINE = 1, KIND_NWDIST = 2 };
+static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, int kind, int gap_extend,
                              const uint8_t* seq_bytes, const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a,
                              const uint32_t* pair_b, uint64_t n_pairs, int want_end_cells, pwa_batch** out) try {
     if (!ctx || !out) return PWA_E_INVALID;
     *out = nullptr;
-    if (affine && want_end_cells) return fail(ctx, PWA_E_INVALID, "end cells are not defined for the affine score pass");
+    const bool affine = kind == KIND_AFFINE, nwdist = kind == KIND_NWDIST;
+    if ((affine || nwdist) && want_end_cells) return fail(ctx, PWA_E_INVALID, "end cells are not defined for this pass");
     if (mode != PWA_MODE_NW && mode != PWA_MODE_SW) return fail(ctx, PWA_E_INVALID, "unknown mode");
     if (!seq_off || (n_pairs && (!pair_a || !pair_b))) return fail(ctx, PWA_E_INVALID, "null input");
     if (n_seq && !seq_bytes && seq_off[n_seq] != 0) return fail(ctx, PWA_E_INVALID, "null seq_bytes");
@@ -363,7 +371,9 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         const uint64_t n = slen(pair_a[k]), m = slen(pair_b[k]);
         if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
         if (n == 0 || m == 0) {
-            if (affine) {   // hw3.cpp:39-52: V[0][0] = 0, F[n][0] = Go + Ge(n-1), E[0][m] = Go + Ge(m-1)
+            if (nwdist) {   // hw4.cpp:21-28 + 146-152: an all-gap alignment, every column counts
+                b->host_scores[k] = (int32_t)(n + m);
+            } else if (affine) {   // hw3.cpp:39-52: V[0][0] = 0, F[n][0] = Go + Ge(n-1), E[0][m] = Go + Ge(m-1)
                 b->host_scores[k] = (n + m == 0) ? 0 : (int32_t)((uint32_t)gap + (uint32_t)wrap_mul((int64_t)(n + m - 1), gap_extend));
             } else if (!local) b->host_scores[k] = wrap_mul((int64_t)(n + m), gap);   // dp[n][0] / dp[0][m], hw2.cpp:125-136
             if (b->want_end && !local) {
@@ -416,8 +426,9 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
 
     // ---- engine choice.  The strip engine pads short patterns with rows that match nothing; for SW
     // those rows can only hold values <= real rows if mismatch <= 0 and gap <= 0.
-    const bool strips_ok = affine || (!b->want_end && (!local || (mismatch <= 0 && gap <= 0)));
+    const bool strips_ok = affine || nwdist || (!b->want_end && (!local || (mismatch <= 0 && gap <= 0)));
     b->affine = affine;
+    b->nwdist = nwdist;
     auto fits8 = [](int v) { return v >= -128 && v <= 127; };
     b->use_strips = strips_ok;
 
@@ -425,7 +436,14 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
     int score_path = SC_CMP;
     int kmode = local ? BM_SW : BM_NW;
     int tab_match = match, tab_mismatch = mismatch;
-    if (affine) {
+    if (nwdist) {
+        kmode = BM_DIST;
+        tab_match = match - gap;       // the rows store H + gap: the diagonal consumer takes the gap back out
+        tab_mismatch = mismatch - gap;
+        if (n_alpha <= 7 && fits8(tab_match) && fits8(tab_mismatch)) score_path = SC_PERM;
+        if (score_path == SC_CMP && absent_byte < 0)
+            return fail(ctx, PWA_E_INVALID, "distance pass: the texts use all 256 byte values, no padding symbol left");
+    } else if (affine) {
         // Ge(i+j)-shifted form when every value stays far inside int32 (the sentinels are -2^29 there)
         const int64_t amax = std::max<int64_t>({std::llabs((long long)match), std::llabs((long long)mismatch),
                                                 std::llabs((long long)gap), std::llabs((long long)gap_extend)});
@@ -531,7 +549,8 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         b->kern = find_batch_kernel(R, kmode, score_path);
         if (!b->kern) return fail(ctx, PWA_E_INVALID, "internal: no kernel instantiation");
         b->kernel_name = b->kern->name;
-        const void* kfn = affine ? reinterpret_cast<const void*>(b->kern->afn) : reinterpret_cast<const void*>(b->kern->fn);
+        const void* kfn = nwdist ? reinterpret_cast<const void*>(b->kern->dfn)
+                                 : (affine ? reinterpret_cast<const void*>(b->kern->afn) : reinterpret_cast<const void*>(b->kern->fn));
 
         std::sort(ht.begin(), ht.end(), [&](const HostTask& x, const HostTask& y) {   // longest first
             const uint64_t cx = (x.maxlen + R - 1) / R * slen(x.text), cy = (y.maxlen + R - 1) / R * slen(y.text);
@@ -569,7 +588,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         per_cu = std::max(1, std::min(per_cu, 32));
         b->grid = (uint32_t)std::min<uint64_t>(nt, (uint64_t)ctx->num_cu * per_cu);
         // int32 per half: one (affine: two) int4 per lane per 4-column block
-        const uint64_t half = ((max_strips > 1) ? ((max_m + 3) / 4 + 1) * 256 : 256) * (affine ? 2 : 1);
+        const uint64_t half = ((max_strips > 1) ? ((max_m + 3) / 4 + 1) * 256 : 256) * ((affine || nwdist) ? 2 : 1);
         HIPC(ctx, b->hand.alloc((size_t)b->grid * 2 * half * sizeof(int32_t)));
 
         BatchParams& P = b->bp;
@@ -634,15 +653,33 @@ extern "C" {
 int pwa_batch_create(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* seq_bytes,
                      const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
                      uint64_t n_pairs, int want_end_cells, pwa_batch** out) {
-    return batch_create_impl(ctx, mode, match, mismatch, gap, false, 0, seq_bytes, seq_off, n_seq, pair_a, pair_b, n_pairs,
+    return batch_create_impl(ctx, mode, match, mismatch, gap, KIND_LINEAR, 0, seq_bytes, seq_off, n_seq, pair_a, pair_b, n_pairs,
                              want_end_cells, out);
 }
 
 int pwa_affine_batch_create(pwa_ctx* ctx, int match, int mismatch, int gap_open, int gap_extend, const uint8_t* seq_bytes,
                             const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
                             uint64_t n_pairs, pwa_batch** out) {
-    return batch_create_impl(ctx, PWA_MODE_NW, match, mismatch, gap_open, true, gap_extend, seq_bytes, seq_off, n_seq, pair_a,
+    return batch_create_impl(ctx, PWA_MODE_NW, match, mismatch, gap_open, KIND_AFFINE, gap_extend, seq_bytes, seq_off, n_seq, pair_a,
                              pair_b, n_pairs, 0, out);
+}
+
+int pwa_nwdist_batch_create(pwa_ctx* ctx, int match, int mismatch, int gap, const uint8_t* seq_bytes, const uint64_t* seq_off,
+                            uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b, uint64_t n_pairs, pwa_batch** out) {
+    return batch_create_impl(ctx, PWA_MODE_NW, match, mismatch, gap, KIND_NWDIST, 0, seq_bytes, seq_off, n_seq, pair_a, pair_b,
+                             n_pairs, 0, out);
+}
+
+int pwa_distances(pwa_ctx* ctx, int match, int mismatch, int gap, const uint8_t* seq_bytes, const uint64_t* seq_off, uint32_t n_seq,
+                  const uint32_t* pair_a, const uint32_t* pair_b, uint64_t n_pairs, int32_t* dist_out) {
+    if (!ctx || !dist_out) return PWA_E_INVALID;
+    pwa_batch* b = nullptr;
+    int rc = pwa_nwdist_batch_create(ctx, match, mismatch, gap, seq_bytes, seq_off, n_seq, pair_a, pair_b, n_pairs, &b);
+    if (rc != PWA_OK) return rc;
+    rc = pwa_batch_run(b, nullptr);
+    if (rc == PWA_OK) rc = pwa_batch_fetch(b, dist_out, nullptr, nullptr);
+    pwa_batch_destroy(b);
+    return rc;
 }
 
 int pwa_scores_affine(pwa_ctx* ctx, int match, int mismatch, int gap_open, int gap_extend, const uint8_t* seq_bytes,
@@ -668,7 +705,14 @@ int pwa_batch_run(pwa_batch* b, void* stream_v) {
     if (b->n_live) {
         if (b->use_strips) {
             HIPC(ctx, hipMemsetAsync(b->queue.p, 0, 16, st));
-            if (b->affine) {
+            if (b->nwdist) {
+                NwDistParams dp;
+                dp.b = b->bp;
+                dp.tab2_lo = 0x000000ffu;   // selector 0 (symbols equal) -> -1, every other selector -> 0
+                dp.tab2_hi = 0u;
+                dp.scores2 = nullptr;
+                hipLaunchKernelGGL(b->kern->dfn, dim3(b->grid), dim3(64), 0, st, dp);
+            } else if (b->affine) {
                 AffineParams ap;
                 ap.b = b->bp;
                 ap.go = b->aff_go;

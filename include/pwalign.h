@@ -124,6 +124,24 @@ int pwa_scores_affine(pwa_ctx *ctx, int match, int mismatch, int gap_open, int g
                       uint64_t n_pairs, int32_t *score_out);
 
 /*
+ * The all-pairs step of the sibling program /root/reference/hw4/hw4.cpp (138-159): per pair a
+ * Needleman-Wunsch alignment with hw4's tie-break (diag >= up >= left, hw4.cpp:36-47 -- not hw2's) and
+ * the number of alignment columns that hold a gap or a mismatch (146-152).  dist_out[k] is that count
+ * for pair k (pair_a = sequence1 = rows, pair_b = sequence2 = columns).  No traceback is stored: the
+ * kernel carries the distance of the chosen path through the DP.  The batch object behaves like any
+ * other (run / d_scores / fetch / info / destroy; no end cells).
+ */
+int pwa_nwdist_batch_create(pwa_ctx *ctx, int match, int mismatch, int gap, const uint8_t *seq_bytes,
+                            const uint64_t *seq_off, uint32_t n_seq, const uint32_t *pair_a, const uint32_t *pair_b,
+                            uint64_t n_pairs, pwa_batch **out);
+int pwa_distances(pwa_ctx *ctx, int match, int mismatch, int gap, const uint8_t *seq_bytes, const uint64_t *seq_off,
+                  uint32_t n_seq, const uint32_t *pair_a, const uint32_t *pair_b, uint64_t n_pairs, int32_t *dist_out);
+/* Host-side UPGMA + Newick of hw4.cpp:162-228 over a dense symmetric n x n matrix of doubles (no GPU
+ * work).  Writes the NUL-terminated tree "(...):0.0;" into out; *needed receives the size required
+ * (PWA_E_CAPACITY when cap is too small; call with cap = 0 to size the buffer). */
+int pwa_upgma_newick(const double *dist, const char *const *names, uint32_t n, char *out, uint64_t cap, uint64_t *needed);
+
+/*
  * Full alignment of ONE pair: matrix fill with the traceback band in HBM + traceback walk on
  * the device.  Replaces one call of hw2.cpp:118 / hw2.cpp:192 up to (not including) the string
  * post-processing prepareCigarString / prepareMDZString (59-116), which stays on the host.
