@@ -40,7 +40,8 @@ HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s 
 VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # VALU instructions per evaluated DP cell of each instantiation: SQ_INSTS_VALU x 64 / padded cells from the
 # rocprofv3 PMC pass (c3: 5.02, c4: 2.53; profiles/), the others counted in the gfx950 ISA of the column block
-VALU_PER_CELL = {"BM_AFFS,SC_PERM": 5.6, "BM_AFFS,SC_CMP": 7.6, "BM_AFF,SC_PERM": 7.6, "BM_AFF,SC_CMP": 9.6,
+VALU_PER_CELL = {"SC_PERM": 10.75, "SC_CMP": 12.0,   # batch_nwdist_kernel<R,SCORE> (hw4)
+                 "BM_AFFS,SC_PERM": 5.6, "BM_AFFS,SC_CMP": 7.6, "BM_AFF,SC_PERM": 7.6, "BM_AFF,SC_CMP": 9.6,
                  "BM_SW,SC_PERM": 5.02, "BM_SW,SC_CMP": 6.9, "BM_NW,SC_PERM": 4.5, "BM_NW,SC_CMP": 6.5,
                  "BM_NWG,SC_PERM": 2.53, "BM_NWG,SC_CMP": 4.5}
 
@@ -87,6 +88,8 @@ class DevPtr:
 def _cpu_one(mode, O, kind, p, t, scoring):
     if mode == "affine":
         return (O.ref_affine_score if kind == "reference" else O.affine_score)(p, t, *scoring)
+    if mode == "nwdist":
+        return O.ref_nw_distance(p, t, *scoring) if kind == "reference" else O.nw_distance(p, t, *scoring)[0]
     return (O.ref_align(mode, p, t, *scoring) if kind == "reference" else O.align(mode, p, t, *scoring))["score"]
 
 
@@ -95,7 +98,7 @@ def cpu_baseline(mode, pairs, seqs, scoring, budget_s=12.0, max_pairs=1024):
     "port") on a bounded sample of the same workload, 1 thread; then all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    kind = "reference" if (O.have_ref3() if mode == "affine" else O.have_ref()) else "port"
+    kind = "reference" if (O.have_ref3() if mode == "affine" else O.have_ref4() if mode == "nwdist" else O.have_ref()) else "port"
     fn = lambda p, t: _cpu_one(mode, O, kind, p, t, scoring)   # noqa: E731
     t0 = time.perf_counter()
     cells, scores = 0, []
@@ -108,6 +111,7 @@ def cpu_baseline(mode, pairs, seqs, scoring, budget_s=12.0, max_pairs=1024):
     out = {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": kind,
            "sample": "first %d pairs of the workload (%.3g cells, %.1f s), %s, g++ -O2"
                      % (len(scores), cells, dt, "six int matrices as hw3.cpp" if mode == "affine"
+                        else "int+char matrices + traceback strings as hw4.cpp" if mode == "nwdist"
                         else "full int+char matrices as hw2.cpp")}
     # all host cores: one process per core over disjoint shards (the reference itself is single-threaded)
     try:
@@ -176,13 +180,21 @@ def build_hw3(rank, world, n_seq=1024, slen=1000):
     return "affine", seqs, pa, pb, (5, -4, -16, -4), desc
 
 
+def build_hw4(rank, world, n_seq=1024, slen=1000):
+    """hw4.cpp all-pairs step (138-159): NW with hw4's tie-break + gap/mismatch column count."""
+    mode, seqs, pa, pb, _, desc = build_c4(rank, world, n_seq, slen)
+    desc["workload"] = ("hw4: all-pairs NW + traceback-derived distance (hw4.cpp:138-159), %d seq x %d bp (%d pairs) sharded "
+                        "over %d GPU(s), 1/-1/-1" % (n_seq, slen, desc["pairs_total"], world))
+    return "nwdist", seqs, pa, pb, (1, -1, -1), desc
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c2", "c2b", "c5", "hw3", "g"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c2", "c2b", "c5", "hw3", "hw4", "g"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="reduced sizes (functional check only; line is marked invalid)")
     args = ap.parse_args()
@@ -216,16 +228,23 @@ def main():
         kw = dict(n_patterns=256, n_texts=16, tlen=2000) if args.small else {}
         mode, seqs, pa, pb, scoring, desc = build_c3(rank, **kw)
         scaling = "weak"
-    elif args.workload == "hw3":
+    elif args.workload in ("hw3", "hw4"):
         kw = dict(n_seq=128) if args.small else {}
-        mode, seqs, pa, pb, scoring, desc = build_hw3(rank, world, **kw)
+        mode, seqs, pa, pb, scoring, desc = (build_hw3 if args.workload == "hw3" else build_hw4)(rank, world, **kw)
         scaling = "strong"
     else:
         kw = dict(n_seq=128) if args.small else {}
         mode, seqs, pa, pb, scoring, desc = build_c4(rank, world, **kw)
         scaling = "strong"
 
-    batch = ctx.batch_affine(seqs, pa, pb, *scoring) if mode == "affine" else ctx.batch(mode, seqs, pa, pb, *scoring)
+    def make_batch():
+        if mode == "affine":
+            return ctx.batch_affine(seqs, pa, pb, *scoring)
+        if mode == "nwdist":
+            return ctx.batch_distances(seqs, pa, pb, *scoring)
+        return ctx.batch(mode, seqs, pa, pb, *scoring)
+
+    batch = make_batch()
     info = batch.info()
     n_pairs = len(pa)
 
@@ -249,7 +268,7 @@ def main():
     def step():
         batch.run(stream)
         if use_dist:   # RCCL all-gather of the per-pair int32 scores over xGMI (the path's only collective)
-            if args.workload in ("c4", "hw3"):
+            if args.workload in ("c4", "hw3", "hw4"):
                 state["gathered"] = shard.all_gather_scores(mine, n_total, per, dist)
             else:       # weak scaling: every rank contributes n_pairs scores of its own texts
                 if state["gathered"] is None:
@@ -331,6 +350,8 @@ def main():
         "metric": "GCUPS (billion DP cells/s) SW linear-gap, 1/2/4/8xMI355X; bit-exact vs hw2.cpp"
                   if args.workload == "c3" else ("GCUPS (billion DP cells/s) affine-gap all-pairs score pass; bit-exact vs hw3.cpp"
                                                  if args.workload == "hw3" else
+                                                 "GCUPS (billion DP cells/s) NW + traceback-derived distance, all pairs; bit-exact vs hw4.cpp"
+                                                 if args.workload == "hw4" else
                                                  "GCUPS (billion DP cells/s) NW linear-gap all-pairs; bit-exact vs hw2.cpp"),
         "value": gcups, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
@@ -355,7 +376,7 @@ def main():
         t1 = time.perf_counter()
         again = None
         if again is None:
-            b2 = ctx.batch_affine(seqs, pa, pb, *scoring) if mode == "affine" else ctx.batch(mode, seqs, pa, pb, *scoring)
+            b2 = make_batch()
             b2.run()
             again = b2.fetch(numpy_out=True)
             b2.close()
