@@ -123,7 +123,10 @@ __device__ __forceinline__ void dp_block(int (&H)[R], const uint32_t (&pk)[R / 4
 // and only ONE wave fits per SIMD -- which halves VALU throughput (one wave issues every 4 cycles).
 constexpr int strip_waves_per_simd(int R) { return R > 104 ? 2 : (R > 80 ? 3 : 4); }
 
-template <int R, int MODE, int SCORE>
+// MULTI = false: every task of the launch is a single strip -- the hand-off row accesses are compiled out
+// (with them, each wave parks an unconditional 1 KiB load + store per 4 columns on an L2-resident dummy
+// block: harmless for speed, but it shows up as ~45 MB of HBM traffic per C3 launch).
+template <int R, int MODE, int SCORE, bool MULTI>
 __global__ __launch_bounds__(64, strip_waves_per_simd(R)) void batch_scores_kernel(const BatchParams P) {
     constexpr int Q = R / 4;
     const int lane = threadIdx.x;
@@ -182,13 +185,14 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R)) void batch_scores_kern
             const size_t in_stride = has_top ? 64 : 0, out_stride = has_bot ? 64 : 0;
             const int4* hin4 = reinterpret_cast<const int4*>(hin) + lane;
             int4* hout4 = reinterpret_cast<int4*>(hout) + lane;
-            int4 tnext = hin4[0];
+            int4 tnext = make_int4(0, 0, 0, 0);
+            if (MULTI) tnext = hin4[0];
             uint32_t cwn = tx[0];
             for (int jb = 0; jb < nblk; ++jb) {
                 const uint32_t cw = cwn;
                 const int4 tcur = tnext;
                 cwn = tx[jb + 1];   // arena slack makes the over-read safe
-                tnext = hin4[(size_t)(jb + 1) * in_stride];
+                if (MULTI) tnext = hin4[(size_t)(jb + 1) * in_stride];
                 int top[4], bot[4];
                 uint32_t cs[4];
 #pragma unroll
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R)) void batch_scores_kern
                     for (int k = 0; k < 4; ++k) top[k] = has_top ? tl[k] : ((MODE == BM_NW) ? mulw(4 * jb + k + 1, P.gap) : 0);   // hw2.cpp:131-136
                 }
                 dp_block<R, 4, MODE, SCORE>(H, pk, cs, top, topprev, bot, best, P);
-                hout4[(size_t)jb * out_stride] = make_int4(bot[0], bot[1], bot[2], bot[3]);
+                if (MULTI) hout4[(size_t)jb * out_stride] = make_int4(bot[0], bot[1], bot[2], bot[3]);
             }
             if (rem > 0) {
                 uint32_t cw = cwn;
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R)) void batch_scores_kern
                     t1 = t2;
                     int bot1[1];
                     dp_block<R, 1, MODE, SCORE>(H, pk, cs1, top1, topprev, bot1, best, P);
-                    hout[((size_t)nblk * out_stride + lane) * 4 + k] = bot1[0];
+                    if (MULTI) hout[((size_t)nblk * out_stride + lane) * 4 + k] = bot1[0];
                 }
             }
             // ---- NW: dp[n][m] sits in this strip for the lanes whose pattern ends here (hw2.cpp:186)

@@ -83,12 +83,14 @@ typedef void (*nwdist_kernel_t)(const NwDistParams);
 enum { BM_AFF = 3, BM_AFFS = 4, BM_DIST = 5 };   // affine (hw3) plain / shifted, hw4 NW + distance; 0..2: batch_scores.hip.h
 struct BatchKernelEntry {
     int R, mode, score;
-    batch_kernel_t fn;
+    batch_kernel_t fn;       // multi-strip form (strip hand-off rows through HBM)
     const char* name;
     affine_kernel_t afn = nullptr;
     nwdist_kernel_t dfn = nullptr;
+    batch_kernel_t fn_single = nullptr;   // every task a single strip: no hand-off accesses at all
 };
-#define BK(R, M, S) {R, M, S, batch_scores_kernel<R, M, S>, "batch_scores_kernel<R=" #R "," #M "," #S ">"}
+#define BK(R, M, S) {R, M, S, batch_scores_kernel<R, M, S, true>, "batch_scores_kernel<R=" #R "," #M "," #S ">", nullptr, nullptr, \
+                     batch_scores_kernel<R, M, S, false>}
 const BatchKernelEntry kBatchKernels[] = {
     BK(76, BM_SW, SC_PERM),   BK(104, BM_SW, SC_PERM),
     BK(64, BM_SW, SC_PERM),   BK(128, BM_SW, SC_PERM),  BK(152, BM_SW, SC_PERM),
@@ -245,7 +247,7 @@ struct pwa_batch {
     bool use_strips = false;
     const BatchKernelEntry* kern = nullptr;
     BatchParams bp{};
-    bool affine = false, nwdist = false;
+    bool affine = false, nwdist = false, single_strip = false;
     int32_t aff_go = 0, aff_ge = 0, aff_neg = 0;
     uint32_t grid = 0;
     DevBuf arena, tasks, slot_poff, slot_plen, slot_out, hand, queue, scores;
@@ -549,9 +551,6 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         b->kern = find_batch_kernel(R, kmode, score_path);
         if (!b->kern) return fail(ctx, PWA_E_INVALID, "internal: no kernel instantiation");
         b->kernel_name = b->kern->name;
-        const void* kfn = nwdist ? reinterpret_cast<const void*>(b->kern->dfn)
-                                 : (affine ? reinterpret_cast<const void*>(b->kern->afn) : reinterpret_cast<const void*>(b->kern->fn));
-
         std::sort(ht.begin(), ht.end(), [&](const HostTask& x, const HostTask& y) {   // longest first
             const uint64_t cx = (x.maxlen + R - 1) / R * slen(x.text), cy = (y.maxlen + R - 1) / R * slen(y.text);
             if (cx != cy) return cx > cy;
@@ -583,6 +582,9 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         HIPC(ctx, b->slot_out.alloc(nt * 64 * 4));
         HIPC(ctx, hipMemcpy(b->slot_out.p, sout.data(), nt * 64 * 4, hipMemcpyHostToDevice));
 
+        b->single_strip = !affine && !nwdist && max_strips == 1 && b->kern->fn_single != nullptr;
+        const void* kfn = b->single_strip ? reinterpret_cast<const void*>(b->kern->fn_single) : nwdist ? reinterpret_cast<const void*>(b->kern->dfn)
+                                 : (affine ? reinterpret_cast<const void*>(b->kern->afn) : reinterpret_cast<const void*>(b->kern->fn));
         int per_cu = 0;
         HIPC(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64, 0));
         per_cu = std::max(1, std::min(per_cu, 32));
@@ -720,7 +722,7 @@ int pwa_batch_run(pwa_batch* b, void* stream_v) {
                 ap.neg = b->aff_neg;
                 hipLaunchKernelGGL(b->kern->afn, dim3(b->grid), dim3(64), 0, st, ap);
             } else {
-                hipLaunchKernelGGL(b->kern->fn, dim3(b->grid), dim3(64), 0, st, b->bp);
+                hipLaunchKernelGGL(b->single_strip ? b->kern->fn_single : b->kern->fn, dim3(b->grid), dim3(64), 0, st, b->bp);
             }
             HIPC(ctx, hipGetLastError());
         } else {
