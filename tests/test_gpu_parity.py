@@ -341,3 +341,46 @@ def test_error_reporting(ctx, pkg):
     assert rc == -5 and b"ops_cap" in L.pwa_last_error(ctx._h)   # PWA_E_CAPACITY
     rc = L.pwa_align(ctx._h, 7, 1, -1, -1, b"A", 1, b"A", 1, C.byref(score), ops, 4, C.byref(n_ops), None, None)
     assert rc == -1
+
+
+# ------------------------------------------------------------------ BASELINE.json full sizes, size-independent properties
+def test_full_size_c3_batch_properties(ctx):
+    """C3 at full size (4096 x 150 bp  X  256 x 10 kbp = 1 048 576 pairs): a seeded sample of 384 pairs equals the
+    oracle, every score respects 0 <= s <= 150, and the result does not depend on the order of the pair list."""
+    import numpy as np
+    pats = [O.gen(1, 0, p, 150) for p in range(4096)]
+    txts = [O.gen(1, 1, t, 10000) for t in range(256)]
+    seqs = pats + txts
+    pa = np.repeat(np.arange(4096, dtype=np.uint32), 256)
+    pb = np.tile(np.arange(256, dtype=np.uint32) + np.uint32(4096), 4096)
+    b = ctx.batch("sw", seqs, pa, pb, 1, -1, -1)
+    b.run()
+    s = b.fetch(numpy_out=True)
+    b.close()
+    assert s.min() >= 0 and s.max() <= 150
+    rng = np.random.default_rng(3)
+    for k in rng.choice(len(pa), 384, replace=False):
+        assert int(s[k]) == O.score("sw", seqs[pa[k]], seqs[pb[k]], 1, -1, -1)[0], k
+    perm = rng.permutation(len(pa))
+    b2 = ctx.batch("sw", seqs, np.ascontiguousarray(pa[perm]), np.ascontiguousarray(pb[perm]), 1, -1, -1)
+    b2.run()
+    s2 = b2.fetch(numpy_out=True)
+    b2.close()
+    assert np.array_equal(s2, s[perm])
+    assert int(s.astype(np.int64).sum()) == 35376135   # checksum of the bench line (bit-exact vs hw2.cpp on its sample)
+
+
+def test_full_size_c5_pair_properties(ctx):
+    """C5 at full size (NW 100k x 100k, 10 GB traceback band): the returned path is a complete global path
+    (#M+#D = n, #M+#I = m, ends in (0,0)), it re-scores to the returned score, NW(p,t) == NW(t,p), and the
+    score equals the oracle's score-only DP."""
+    n = m = 100000
+    p, t = O.gen(1, 0, 0, n), O.gen(1, 1, 0, m)
+    got = ctx.align("nw", p, t, 1, -1, -1, raw=True)
+    ops = got["ops"]
+    assert tuple(got["end"]) == (n, m) and tuple(got["start"]) == (0, 0)
+    assert ops.count(b"M") + ops.count(b"D") == n and ops.count(b"M") + ops.count(b"I") == m
+    tot, start = _path_score(p, t, ops, got["end"], 1, -1, -1)
+    assert tot == got["score"] and start == (0, 0)
+    assert ctx.align("nw", t, p, 1, -1, -1, raw=True)["score"] == got["score"]
+    assert got["score"] == O.score("nw", p, t, 1, -1, -1)[0] == 11391   # the oracle's O(m)-memory DP: ~15 s of CPU
