@@ -384,3 +384,25 @@ def test_full_size_c5_pair_properties(ctx):
     assert tot == got["score"] and start == (0, 0)
     assert ctx.align("nw", t, p, 1, -1, -1, raw=True)["score"] == got["score"]
     assert got["score"] == O.score("nw", p, t, 1, -1, -1)[0] == 11391   # the oracle's O(m)-memory DP: ~15 s of CPU
+
+
+def test_pipeline_handoff_under_uneven_concurrent_load(ctx):
+    """Many multi-super-stripe pairs of very different shapes in ONE launch: every inter-workgroup hand-off
+    (helper wave, sc1 rows + progress counters) runs while other workgroups stream bands at different rates.
+    Every op of every pair must equal the oracle's."""
+    rng = random.Random(2024)
+    seqs = []
+    for _ in range(40):
+        n = rng.choice([600, 700, 1030, 1500, 2100, 3000])
+        seqs.append(bytes(rng.choice(b"ACGT") for _ in range(n + rng.randint(0, 40))))
+    for _ in range(12):
+        seqs.append(bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 300))))
+    pa = [rng.randrange(40) for _ in range(70)] + [40 + rng.randrange(12) for _ in range(10)]
+    pb = [rng.randrange(52) for _ in range(80)]
+    for mode in ("nw", "sw"):
+        res = ctx.align_batch(mode, seqs, pa, pb, 1, -1, -1)
+        for k, r in enumerate(res):
+            want = O.align(mode, seqs[pa[k]], seqs[pb[k]], 1, -1, -1, compact=True)
+            assert r["score"] == want["score"], (mode, k)
+            assert r["ops"] == want["ops"], (mode, k, len(seqs[pa[k]]), len(seqs[pb[k]]))
+            assert tuple(r["end"]) == tuple(want["end"]) and tuple(r["start"]) == tuple(want["start"])
