@@ -17,7 +17,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpwalign.so")
+LIB_PATH = os.environ.get("PWA_LIB") or os.path.join(_HERE, "libpwalign.so")   # PWA_LIB: A/B builds in experiments
 CLI_PATH = os.path.join(_HERE, "host", "hw2_amd")
 CLI4_PATH = os.path.join(_HERE, "host", "hw4_amd")
 
@@ -27,7 +27,7 @@ EXPORTS = [
     "pwa_version", "pwa_strerror", "pwa_ctx_create", "pwa_ctx_destroy", "pwa_last_error", "pwa_ctx_set_score_band", "pwa_scores",
     "pwa_batch_create", "pwa_affine_batch_create", "pwa_scores_affine", "pwa_nwdist_batch_create", "pwa_distances", "pwa_upgma_newick", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_set_d_scores", "pwa_batch_fetch", "pwa_batch_info",
     "pwa_batch_last_ms", "pwa_batch_run_times", "pwa_batch_destroy", "pwa_align", "pwa_align_matrices", "pwa_align_last_stats", "pwa_align_batch",
-    "pwa_cigar_bound", "pwa_mdz_bound", "pwa_format_alignment",
+    "pwa_cigar_bound", "pwa_mdz_bound", "pwa_format_alignment", "pwa_alignment_overlap",
 ]
 
 
@@ -85,6 +85,7 @@ def lib():
     L.pwa_cigar_bound.restype = C.c_uint64
     L.pwa_mdz_bound.argtypes = [C.c_uint64]
     L.pwa_mdz_bound.restype = C.c_uint64
+    L.pwa_alignment_overlap.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, u64p, i32p]
     L.pwa_format_alignment.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, vp, vp, i32p]
     _lib = L
     return L
@@ -104,6 +105,18 @@ def pack_sequences(seqs):
         tot += len(s)
     off[len(seqs)] = tot
     return b"".join(seqs), off, seqs
+
+
+def alignment_overlap(pattern, text, ops, end):
+    """overlapLongestExactMatch (hw2.cpp:267-278) from the op list alone."""
+    L = lib()
+    pattern, text, ops = _b(pattern), _b(text), _b(ops)
+    ov = C.c_int32(0)
+    endc = (C.c_uint64 * 2)(end[0], end[1])
+    rc = L.pwa_alignment_overlap(pattern, len(pattern), text, len(text), ops, len(ops), endc, C.byref(ov))
+    if rc != 0:
+        raise PwaError("pwa_alignment_overlap: %s" % L.pwa_strerror(rc).decode())
+    return ov.value
 
 
 def format_alignment(pattern, text, ops, end):

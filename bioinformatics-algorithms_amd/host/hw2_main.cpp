@@ -168,18 +168,26 @@ int main(int argc, char* argv[]) {
             }
             int best_overlap = -1000000;   // hw2.cpp:326
             for (size_t i = 0; i < np; ++i) {   // hw2.cpp:342-350: first strictly larger overlap wins
-                Formatted f;
-                if (!format(patterns[i], references[i], ops.data() + ops_off[i], n_ops[i], &ends[2 * i], f)) {
+                int32_t ov = 0;
+                if (pwa_alignment_overlap(reinterpret_cast<const uint8_t*>(patterns[i].data()), patterns[i].size(),
+                                          reinterpret_cast<const uint8_t*>(references[i].data()), references[i].size(),
+                                          ops.data() + ops_off[i], n_ops[i], &ends[2 * i], &ov) != PWA_OK) {
                     std::cerr << "Error: inconsistent traceback for pair " << i << std::endl;
                     pwa_ctx_destroy(ctx);
                     return 2;
                 }
-                if (f.overlap > best_overlap) {
-                    best_overlap = f.overlap;
+                if (ov > best_overlap) {
+                    best_overlap = ov;
                     best_index = (int)i;
                     best_score_field = scores[i];
-                    best = f;
                 }
+            }
+            // only the winner's strings are ever printed (hw2.cpp:379-385)
+            if (best_index >= 0 && !format(patterns[best_index], references[best_index], ops.data() + ops_off[best_index],
+                                           n_ops[best_index], &ends[2 * best_index], best)) {
+                std::cerr << "Error: inconsistent traceback for pair " << best_index << std::endl;
+                pwa_ctx_destroy(ctx);
+                return 2;
             }
         } else {
             std::vector<int32_t> scores(np);

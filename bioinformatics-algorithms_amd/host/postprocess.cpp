@@ -29,6 +29,45 @@ extern "C" {
 uint64_t pwa_cigar_bound(uint64_t n_ops) { return 2 * n_ops + 24; }
 uint64_t pwa_mdz_bound(uint64_t n_ops) { return 3 * n_ops + 24; }
 
+// hw2.cpp:344 needs overlapLongestExactMatch (267-278) of EVERY pair in -g mode but the strings of the
+// best pair only: this walks the op list once, without building the gapped strings.
+int pwa_alignment_overlap(const uint8_t* pattern, uint64_t n, const uint8_t* text, uint64_t m, const uint8_t* ops,
+                          uint64_t n_ops, const uint64_t end_cell[2], int32_t* overlap) {
+    if (!end_cell || (n_ops && !ops) || !overlap) return PWA_E_INVALID;
+    uint64_t i = end_cell[0], j = end_cell[1];
+    if (i > n || j > m) return PWA_E_INVALID;
+    int32_t best = 0, cur = 0;   // a run is the same forwards and backwards
+    for (uint64_t k = 0; k < n_ops; ++k) {
+        switch (ops[k]) {
+            case 'M':
+                if (i == 0 || j == 0) return PWA_E_INVALID;
+                --i;
+                --j;
+                // hw2.cpp:270: both non-gap and equal; a literal '-' in a sequence never counts (it fails the != '-' test)
+                if (pattern[i] == text[j] && pattern[i] != '-') {
+                    if (++cur > best) best = cur;
+                } else {
+                    cur = 0;
+                }
+                break;
+            case 'D':
+                if (i == 0) return PWA_E_INVALID;
+                --i;
+                cur = 0;
+                break;
+            case 'I':
+                if (j == 0) return PWA_E_INVALID;
+                --j;
+                cur = 0;
+                break;
+            default:
+                return PWA_E_INVALID;
+        }
+    }
+    *overlap = best;
+    return PWA_OK;
+}
+
 int pwa_format_alignment(const uint8_t* pattern, uint64_t n, const uint8_t* text, uint64_t m, const uint8_t* ops,
                          uint64_t n_ops, const uint64_t end_cell[2], char* aligned_pattern, char* aligned_reference,
                          char* cigar, char* mdz, int32_t* overlap) {

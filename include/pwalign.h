@@ -194,6 +194,10 @@ int pwa_align_batch(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, co
  * 'I' = '-' against text char, MD:Z mismatches print the REFERENCE character and deletions
  * print the PATTERN characters.
  */
+/* overlapLongestExactMatch (hw2.cpp:267-278) straight from the op list, without building the strings:
+ * what the -g selection loop (hw2.cpp:342-350) needs for every pair. */
+int pwa_alignment_overlap(const uint8_t *pattern, uint64_t n, const uint8_t *text, uint64_t m, const uint8_t *ops,
+                          uint64_t n_ops, const uint64_t end_cell[2], int32_t *overlap);
 uint64_t pwa_cigar_bound(uint64_t n_ops);
 uint64_t pwa_mdz_bound(uint64_t n_ops);
 int pwa_format_alignment(const uint8_t *pattern, uint64_t n, const uint8_t *text, uint64_t m, const uint8_t *ops,

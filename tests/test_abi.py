@@ -67,6 +67,8 @@ def test_format_alignment_matches_reference(name):
         assert f["aligned_pattern"] == B(rec["aligned_pattern"])
         assert f["aligned_reference"] == B(rec["aligned_reference"])
         assert f["overlap"] == rec["overlap"]
+        assert pkg.alignment_overlap(p, t, o["ops"], o["end"]) == rec["overlap"]
+    assert pkg.alignment_overlap(b"A-C", b"A-C", b"MMM", (3, 3)) == pkg.format_alignment(b"A-C", b"A-C", b"MMM", (3, 3))["overlap"] == 1
 
 
 def test_format_alignment_rejects_inconsistent_input():
