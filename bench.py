@@ -42,6 +42,7 @@ VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # rocprofv3 PMC pass (c3: 5.02, c4: 2.53; profiles/), the others counted in the gfx950 ISA of the column block
 VALU_PER_CELL = {"SC_PERM": 10.75, "SC_CMP": 12.0,   # batch_nwdist_kernel<R,SCORE> (hw4)
                  "BM_AFFS,SC_PERM": 5.6, "BM_AFFS,SC_CMP": 7.6, "BM_AFF,SC_PERM": 7.6, "BM_AFF,SC_CMP": 9.6,
+                 "BM_SWS,SC_PERM": 4.06, "BM_SWS,SC_CMP": 6.06,
                  "BM_SW,SC_PERM": 5.02, "BM_SW,SC_CMP": 6.9, "BM_NW,SC_PERM": 4.5, "BM_NW,SC_CMP": 6.5,
                  "BM_NWG,SC_PERM": 2.53, "BM_NWG,SC_CMP": 4.5}
 

@@ -30,7 +30,12 @@
 
 namespace pwa {
 
-enum { BM_SW = 0, BM_NW = 1, BM_NWG = 2 };   // NWG: NW in gap-shifted space G = H - g(i+j)
+// NWG: NW in gap-shifted space G = H - g(i+j).
+// SWS: SW with a second stored form per row, Hs = max(H + g, 0) (one unsigned saturating subtract).  Both gap
+//      candidates then arrive already floored at 0, so  max(0, t, u+g, l+g) = max3(t, Hs_up, Hs_left)  with
+//      no explicit 0 and no separate "+ g": 3 VALU per cell instead of 4 (+ 1/2 table + 1/2 running best),
+//      at the price of 2R instead of R registers per lane (R <= 96).
+enum { BM_SW = 0, BM_NW = 1, BM_NWG = 2, BM_SWS = 6 };
 enum { SC_PERM = 0, SC_CMP = 1 };
 
 struct BatchTask {
@@ -65,19 +70,24 @@ __device__ __forceinline__ int mulw(int a, int b) { return (int)((unsigned)a * (
 //            out: dp[row0+r+1][j0+C]
 //   top[k]   dp[row0][j0+1+k]  (row above the strip), topprev = dp[row0][j0]
 //   bot[k]   dp[row0+R][j0+1+k]
+__device__ __forceinline__ int usub_sat(int a, int b) {   // max(a - b, 0) for a, b >= 0: v_sub_u32 ... clamp
+    return (int)__builtin_elementwise_sub_sat((unsigned)a, (unsigned)b);
+}
+
 template <int R, int C, int MODE, int SCORE>
-__device__ __forceinline__ void dp_block(int (&H)[R], const uint32_t (&pk)[R / 4], const uint32_t (&cs)[C],
-                                         const int (&top)[C], int& topprev, int (&bot)[C], int& best,
+__device__ __forceinline__ void dp_block(int (&H)[R], int (&Hs)[MODE == BM_SWS ? R : 1], const uint32_t (&pk)[R / 4],
+                                         const uint32_t (&cs)[C], const int (&top)[C], int& topprev, int (&bot)[C], int& best,
                                          const BatchParams& P) {
     constexpr int Q = R / 4;
-    int d[C], u[C];
+    int d[C], u[C], hb[C];
+    const int gap = P.gap;
 #pragma unroll
     for (int k = 0; k < C; ++k) {
         d[k] = (k == 0) ? topprev : top[k - 1];
-        u[k] = top[k];
+        u[k] = (MODE == BM_SWS) ? usub_sat(top[k], -gap) : top[k];
+        hb[k] = 0;
     }
     topprev = top[C - 1];
-    const int gap = P.gap;
     // skewed order: column k runs one quad (4 rows) behind column k-1
 #pragma unroll
     for (int step = 0; step < Q + C - 1; ++step) {
@@ -97,6 +107,17 @@ __device__ __forceinline__ void dp_block(int (&H)[R], const uint32_t (&pk)[R / 4
                     const int l = H[r];            // dp[i][j-1]
                     d[k] = l;
                     int h;
+                    if (MODE == BM_SWS) {
+                        const int ls = Hs[r];                    // max(dp[i][j-1] + g, 0)
+                        h = max(max(t, u[k]), ls);               // = max(0, diag, up, left), hw2.cpp:211
+                        best = max(best, h);
+                        const int hs = usub_sat(h, -gap);
+                        Hs[r] = hs;
+                        H[r] = h;
+                        u[k] = hs;
+                        hb[k] = h;
+                        continue;
+                    }
                     if (MODE == BM_SW) {
                         const int e = addw(max(u[k], l), gap);   // hw2.cpp:209-210
                         h = max(max(t, e), 0);                   // hw2.cpp:211
@@ -109,25 +130,28 @@ __device__ __forceinline__ void dp_block(int (&H)[R], const uint32_t (&pk)[R / 4
                     }
                     H[r] = h;
                     u[k] = h;
+                    hb[k] = h;
                 }
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < C; ++k) bot[k] = u[k];
+    for (int k = 0; k < C; ++k) bot[k] = hb[k];
 }
 
 // Register budget: H[R] + R/4 packed symbols + ~30 live temporaries.  The second launch-bound is the
 // number of waves per SIMD the allocation must leave room for (512 registers per SIMD lane, AGPRs
 // included): without it hipcc parks 12 values in AGPRs at R = 152, the wave allocates 268 registers
 // and only ONE wave fits per SIMD -- which halves VALU throughput (one wave issues every 4 cycles).
-constexpr int strip_waves_per_simd(int R) { return R > 104 ? 2 : (R > 80 ? 3 : 4); }
+constexpr int strip_waves_per_simd(int R, int MODE) {
+    return (MODE == BM_SWS) ? (R > 48 ? 2 : 3) : (R > 104 ? 2 : (R > 80 ? 3 : 4));
+}
 
 // MULTI = false: every task of the launch is a single strip -- the hand-off row accesses are compiled out
 // (with them, each wave parks an unconditional 1 KiB load + store per 4 columns on an L2-resident dummy
 // block: harmless for speed, but it shows up as ~45 MB of HBM traffic per C3 launch).
 template <int R, int MODE, int SCORE, bool MULTI>
-__global__ __launch_bounds__(64, strip_waves_per_simd(R)) void batch_scores_kernel(const BatchParams P) {
+__global__ __launch_bounds__(64, strip_waves_per_simd(R, MODE)) void batch_scores_kernel(const BatchParams P) {
     constexpr int Q = R / 4;
     const int lane = threadIdx.x;
     int32_t* const hand = P.hand + (size_t)blockIdx.x * P.hand_stride;
@@ -172,9 +196,11 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R)) void batch_scores_kern
                 }
             }
             // ---- column 0 of the strip (hw2.cpp:125-130; SW: zeros, 193)
-            int H[R];
+            int H[R], Hs[MODE == BM_SWS ? R : 1];
 #pragma unroll
             for (int r = 0; r < R; ++r) H[r] = (MODE == BM_NW) ? mulw(row0 + r + 1, P.gap) : 0;
+#pragma unroll
+            for (int r = 0; r < (MODE == BM_SWS ? R : 1); ++r) Hs[r] = 0;
             int topprev = (MODE == BM_NW) ? mulw(row0, P.gap) : 0;
 
             const int32_t* hin = hand + (size_t)((s + 1) & 1) * P.hand_half;   // written by strip s-1
@@ -205,7 +231,7 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R)) void batch_scores_kern
 #pragma unroll
                     for (int k = 0; k < 4; ++k) top[k] = has_top ? tl[k] : ((MODE == BM_NW) ? mulw(4 * jb + k + 1, P.gap) : 0);   // hw2.cpp:131-136
                 }
-                dp_block<R, 4, MODE, SCORE>(H, pk, cs, top, topprev, bot, best, P);
+                dp_block<R, 4, MODE, SCORE>(H, Hs, pk, cs, top, topprev, bot, best, P);
                 if (MULTI) hout4[(size_t)jb * out_stride] = make_int4(bot[0], bot[1], bot[2], bot[3]);
             }
             if (rem > 0) {
@@ -220,12 +246,12 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R)) void batch_scores_kern
                     t0 = t1;
                     t1 = t2;
                     int bot1[1];
-                    dp_block<R, 1, MODE, SCORE>(H, pk, cs1, top1, topprev, bot1, best, P);
+                    dp_block<R, 1, MODE, SCORE>(H, Hs, pk, cs1, top1, topprev, bot1, best, P);
                     if (MULTI) hout[((size_t)nblk * out_stride + lane) * 4 + k] = bot1[0];
                 }
             }
             // ---- NW: dp[n][m] sits in this strip for the lanes whose pattern ends here (hw2.cpp:186)
-            if (MODE != BM_SW) {
+            if (MODE != BM_SW && MODE != BM_SWS) {
                 const int rl = n - 1 - row0;
                 if (rl >= 0 && rl < R) {
                     int v = 0;

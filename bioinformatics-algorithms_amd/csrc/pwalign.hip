@@ -93,6 +93,8 @@ struct BatchKernelEntry {
                      batch_scores_kernel<R, M, S, false>}
 const BatchKernelEntry kBatchKernels[] = {
     BK(76, BM_SW, SC_PERM),   BK(104, BM_SW, SC_PERM),
+    BK(40, BM_SWS, SC_PERM),  BK(52, BM_SWS, SC_PERM),  BK(76, BM_SWS, SC_PERM),  BK(96, BM_SWS, SC_PERM),
+    BK(40, BM_SWS, SC_CMP),   BK(52, BM_SWS, SC_CMP),   BK(76, BM_SWS, SC_CMP),   BK(96, BM_SWS, SC_CMP),
     BK(64, BM_SW, SC_PERM),   BK(128, BM_SW, SC_PERM),  BK(152, BM_SW, SC_PERM),
     BK(64, BM_SW, SC_CMP),    BK(128, BM_SW, SC_CMP),   BK(152, BM_SW, SC_CMP),
     BK(64, BM_NW, SC_PERM),   BK(128, BM_NW, SC_PERM),  BK(152, BM_NW, SC_PERM),
@@ -525,13 +527,18 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             p = q;
         }
         // ---- strip height: least padded work, ties to the taller strip
-        int bestR = 0;
+        int bestR = 0, best_mode = kmode;
         long double best_cost = -1;
-        const char* force = std::getenv("PWA_FORCE_R");   // experiments only
+        const char* force = std::getenv("PWA_FORCE_R");      // experiments only
+        const char* force_mode = std::getenv("PWA_FORCE_MODE");
         for (const auto& e : kBatchKernels) {
-            if (e.mode != kmode || e.score != score_path) continue;
+            // SW has two forms: BM_SW (R registers per lane, 5.0 VALU per cell) and BM_SWS (2R registers, 4.06)
+            const bool mode_ok = e.mode == kmode || (kmode == BM_SW && e.mode == BM_SWS);
+            if (!mode_ok || e.score != score_path) continue;
             const int R = e.R;
             if (force && std::atoi(force) != R) continue;
+            if (force_mode && std::atoi(force_mode) != e.mode) continue;
+            const long double w = e.mode == BM_SWS ? 4.06L : (e.mode == BM_SW ? 5.02L : 1.0L);   // VALU per cell
             // evaluated cells + the strip hand-off priced at ~2 cells per column and strip boundary ([gpu]: the
             // 1000-row affine pass is equally fast at R = 32 and 52 but moves 37 % fewer HBM bytes at 52)
             long double cost = 0;
@@ -539,11 +546,14 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
                 const uint64_t strips = (t.maxlen + R - 1) / R;
                 cost += (long double)(strips * R + 2 * (strips - 1)) * (long double)slen(t.text) * 64.0L;
             }
+            cost *= w;
             if (best_cost < 0 || cost < best_cost || (cost == best_cost && R > bestR)) {
                 best_cost = cost;
                 bestR = R;
+                best_mode = e.mode;
             }
         }
+        kmode = best_mode;
         if (bestR == 0) return fail(ctx, PWA_E_INVALID, "internal: no kernel instantiation");
         const int R = bestR;
         b->padded_cells = 0;
