@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lds_sync.hip.h"
+
 namespace pwa {
 
 // NWG: NW in gap-shifted space G = H - g(i+j).
@@ -214,6 +216,10 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R, MODE)) void batch_score
             int4 tnext = make_int4(0, 0, 0, 0);
             if (MULTI) tnext = hin4[0];
             uint32_t cwn = tx[0];
+            // single-strip form: row 0 is 0, but as a literal it makes hipcc split the first row's v_max3_i32 into
+            // unsigned/signed v_max pairs that no longer fuse (+0.7 VALU per cell, [asm]); keep the zero opaque
+            int zero = 0;
+            asm volatile("" : "+v"(zero));
             for (int jb = 0; jb < nblk; ++jb) {
                 const uint32_t cw = cwn;
                 const int4 tcur = tnext;
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R, MODE)) void batch_score
                 {
                     const int tl[4] = {tcur.x, tcur.y, tcur.z, tcur.w};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) top[k] = has_top ? tl[k] : ((MODE == BM_NW) ? mulw(4 * jb + k + 1, P.gap) : 0);   // hw2.cpp:131-136
+                    for (int k = 0; k < 4; ++k) top[k] = has_top ? tl[k] : ((MODE == BM_NW) ? mulw(4 * jb + k + 1, P.gap) : (MULTI ? 0 : zero));   // hw2.cpp:131-136
                 }
                 dp_block<R, 4, MODE, SCORE>(H, Hs, pk, cs, top, topprev, bot, best, P);
                 if (MULTI) hout4[(size_t)jb * out_stride] = make_int4(bot[0], bot[1], bot[2], bot[3]);
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R, MODE)) void batch_score
                     const uint32_t c = cw & 0xffu;
                     cw >>= 8;
                     const uint32_t cs1[1] = {(SCORE == SC_PERM) ? c * 0x01010101u : c};
-                    const int top1[1] = {has_top ? t0 : ((MODE == BM_NW) ? mulw(4 * nblk + k + 1, P.gap) : 0)};
+                    const int top1[1] = {has_top ? t0 : ((MODE == BM_NW) ? mulw(4 * nblk + k + 1, P.gap) : (MULTI ? 0 : zero))};
                     t0 = t1;
                     t1 = t2;
                     int bot1[1];
@@ -266,6 +272,188 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R, MODE)) void batch_score
             if (MODE == BM_NW) sc = nw_score;
             if (MODE == BM_NWG) sc = addw(nw_score, mulw(n + m, P.gap));
             P.scores[outi] = sc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Two waves per task: wave 0 runs strip 0, wave 1 runs strip 1 of the same 64 pairs, CONCURRENTLY, and the
+// strip boundary row goes from one to the other through a ring in LDS (16 blocks of 4 columns, 16 KiB)
+// instead of through HBM.  Used when every task of a launch has at most two strips (the saturating SW
+// form on 150-row patterns: 2 x 76 rows).  Same cells, same instruction count, no hand-off traffic.
+#ifndef PWA_PAIR_RING
+#define PWA_PAIR_RING 16
+#endif
+#ifndef PWA_PAIR_SLEEP
+#define PWA_PAIR_SLEEP 1
+#endif
+#ifndef PWA_PAIR_LAG
+#define PWA_PAIR_LAG 1
+#endif
+constexpr int kPairRing = PWA_PAIR_RING;
+
+template <int R, int MODE, int SCORE, int ROLE>
+__device__ __forceinline__ void pair_strip(const BatchParams& P, const BatchTask& task, int lane, uint32_t poff, int n, int m,
+                                           const uint32_t* tx, uint32_t outi, bool has_bot, int4 (*ring)[64], uint32_t* ready,
+                                           uint32_t* taken, int& best, bool& failed) {
+    constexpr int Q = R / 4;
+    constexpr bool TOP = ROLE == 1;
+    const uint32_t spin_limit = 1u << 26;
+    const int nblk = m >> 2, rem = m & 3;
+    const int row0 = ROLE * R;
+    uint32_t pk[Q];
+    {
+        const uint32_t* pp = reinterpret_cast<const uint32_t*>(P.arena + poff + row0);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int valid = n - (row0 + 4 * q);
+            const uint32_t wd = pp[q];
+            const uint32_t keep = valid >= 4 ? 0xffffffffu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
+            pk[q] = (wd & keep) | (P.pad_word & ~keep);
+        }
+    }
+    int H[R], Hs[MODE == BM_SWS ? R : 1];
+#pragma unroll
+    for (int r = 0; r < R; ++r) H[r] = (MODE == BM_NW) ? mulw(row0 + r + 1, P.gap) : 0;
+#pragma unroll
+    for (int r = 0; r < (MODE == BM_SWS ? R : 1); ++r) Hs[r] = 0;
+    int topprev = (MODE == BM_NW) ? mulw(row0, P.gap) : 0;
+    uint32_t cwn = tx[0];
+    // wave 0 keeps publishing even for a single-strip task (nobody reads): avoids a branch in the loop; the
+    // ring-full wait is skipped by pretending everything was taken
+    const uint32_t never_full = has_bot ? 0u : 0x40000000u;
+    // row 0 of a local alignment is 0, but hipcc must not know: with a literal 0 it rewrites the first row's signed
+    // v_max3_i32 into unsigned/signed v_max pairs that no longer fuse (4.7 instead of 4.0 VALU per cell, [asm])
+    int zero = 0;
+    asm volatile("" : "+v"(zero));
+    uint32_t ready_seen = 0, taken_seen = never_full;   // what this wave last saw of the other wave's progress
+    for (int jb = 0; jb < nblk; ++jb) {
+        const uint32_t cw = cwn;
+        cwn = tx[jb + 1];   // arena slack makes the over-read safe
+        int top[4], bot[4];
+        uint32_t cs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t c = (cw >> (8 * k)) & 0xffu;
+            cs[k] = (SCORE == SC_PERM) ? c * 0x01010101u : c;
+        }
+        if (TOP) {   // the row above comes from wave 0 through the LDS ring
+            if (ready_seen <= (uint32_t)jb) {   // the flag is re-read only when the cached value runs out
+                const uint32_t want = min((uint32_t)jb + PWA_PAIR_LAG, (uint32_t)nblk + (rem > 0));
+                for (uint32_t spins = 0; !failed && (ready_seen = __builtin_amdgcn_readfirstlane(lds_peek(ready))) < want;) {
+                    __builtin_amdgcn_s_sleep(PWA_PAIR_SLEEP);
+                    if (++spins > spin_limit) failed = true;
+                }
+            }
+            const int4 tcur = ring[jb % kPairRing][lane];
+            lds_post(taken, (uint32_t)jb + 1);
+            top[0] = tcur.x; top[1] = tcur.y; top[2] = tcur.z; top[3] = tcur.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) top[k] = (MODE == BM_NW) ? mulw(4 * jb + k + 1, P.gap) : zero;
+        }
+        dp_block<R, 4, MODE, SCORE>(H, Hs, pk, cs, top, topprev, bot, best, P);
+        if (!TOP) {   // hand the strip's bottom row to wave 1
+            if ((int)((uint32_t)jb - taken_seen) >= kPairRing) {
+                for (uint32_t spins = 0; !failed && (int)((uint32_t)jb - (taken_seen = __builtin_amdgcn_readfirstlane(lds_peek(taken)) + never_full)) >= kPairRing;) {
+                    __builtin_amdgcn_s_sleep(PWA_PAIR_SLEEP);
+                    if (++spins > spin_limit) failed = true;
+                }
+            }
+            ring[jb % kPairRing][lane] = make_int4(bot[0], bot[1], bot[2], bot[3]);
+            lds_post(ready, (uint32_t)jb + 1);
+        }
+    }
+    if (rem > 0) {   // the last 1..3 columns
+        uint32_t c4 = cwn;
+        int t0 = 0, t1 = 0, t2 = 0;
+        if (TOP) {
+            for (uint32_t spins = 0; !failed && lds_peek(ready) <= (uint32_t)nblk;) {
+                __builtin_amdgcn_s_sleep(PWA_PAIR_SLEEP);
+                if (++spins > spin_limit) failed = true;
+            }
+            const int4 tcur = ring[nblk % kPairRing][lane];
+            lds_post(taken, (uint32_t)nblk + 1);
+            t0 = tcur.x; t1 = tcur.y; t2 = tcur.z;
+        }
+        int b0 = 0, b1 = 0, b2 = 0;
+#pragma unroll 1
+        for (int k = 0; k < rem; ++k) {
+            const uint32_t c = c4 & 0xffu;
+            c4 >>= 8;
+            const uint32_t cs1[1] = {(SCORE == SC_PERM) ? c * 0x01010101u : c};
+            const int top1[1] = {TOP ? t0 : ((MODE == BM_NW) ? mulw(4 * nblk + k + 1, P.gap) : zero)};
+            t0 = t1;
+            t1 = t2;
+            int bot1[1];
+            dp_block<R, 1, MODE, SCORE>(H, Hs, pk, cs1, top1, topprev, bot1, best, P);
+            b0 = (k == 0) ? bot1[0] : b0;
+            b1 = (k == 1) ? bot1[0] : b1;
+            b2 = (k == 2) ? bot1[0] : b2;
+        }
+        if (!TOP) {
+            for (uint32_t spins = 0; !failed && (int)((uint32_t)nblk - (lds_peek(taken) + never_full)) >= kPairRing;) {
+                __builtin_amdgcn_s_sleep(PWA_PAIR_SLEEP);
+                if (++spins > spin_limit) failed = true;
+            }
+            ring[nblk % kPairRing][lane] = make_int4(b0, b1, b2, 0);
+            lds_post(ready, (uint32_t)nblk + 1);
+        }
+    }
+    if (MODE != BM_SW && MODE != BM_SWS) {
+        const int rl = n - 1 - row0;
+        if (rl >= 0 && rl < R) {
+            int v = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) v = (rl == r) ? H[r] : v;
+            if (outi != 0xffffffffu) P.scores[outi] = (MODE == BM_NWG) ? addw(v, mulw(n + m, P.gap)) : v;
+        }
+    }
+}
+
+template <int R, int MODE, int SCORE>
+__global__ __launch_bounds__(128, strip_waves_per_simd(R, MODE)) void batch_scores_pair_kernel(const BatchParams P) {
+    __shared__ int4 ring[kPairRing][64];
+    __shared__ uint32_t ready, taken, task_sh;
+    __shared__ int best_sh[64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    for (;;) {
+        __syncthreads();   // both waves are done with the previous task's ring
+        if (threadIdx.x == 0) {
+            task_sh = atomicAdd(P.queue, 1u);
+            ready = 0;
+            taken = 0;
+        }
+        __syncthreads();
+        const uint32_t tid = __builtin_amdgcn_readfirstlane(task_sh);
+        if (tid >= P.n_tasks) break;
+
+        const BatchTask task = P.tasks[tid];
+        const int m = (int)task.text_len;
+        const uint32_t* tx = reinterpret_cast<const uint32_t*>(P.arena + task.text_off);
+        const uint32_t slot = task.slot0 + lane;
+        const uint32_t poff = P.slot_poff[slot];
+        const int n = (int)P.slot_plen[slot];
+        const uint32_t outi = P.slot_out[slot];
+        const bool active = (uint32_t)w < task.n_strips;
+        const bool has_bot = task.n_strips > 1;
+        int best = 0;
+        bool failed = false;
+
+        if (active) {
+            // one body per role (ROLE 0: no row above, hands its bottom row on; ROLE 1: takes the row above): the
+            // column loop must not carry role branches -- hipcc then doubles the live H registers and spills
+            if (w == 0) pair_strip<R, MODE, SCORE, 0>(P, task, lane, poff, n, m, tx, outi, has_bot, ring, &ready, &taken, best, failed);
+            else pair_strip<R, MODE, SCORE, 1>(P, task, lane, poff, n, m, tx, outi, false, ring, &ready, &taken, best, failed);
+        }
+        if (failed && lane == 0) __hip_atomic_store(P.queue + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MODE == BM_SW || MODE == BM_SWS) {   // the pair's score is the larger of the two strips' maxima
+            if (w == 0) best_sh[lane] = best;
+            __syncthreads();
+            const uint32_t last = task.n_strips > 1 ? 1u : 0u;
+            if ((uint32_t)w == last && outi != 0xffffffffu) P.scores[outi] = (last == 1) ? max(best, best_sh[lane]) : best;
         }
     }
 }

@@ -34,6 +34,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lds_sync.hip.h"
+
 namespace pwa {
 
 enum { TB_STOP = 0, TB_DIAG = 1, TB_UP = 2, TB_LEFT = 3 };
@@ -186,20 +188,6 @@ __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i
 #pragma unroll
         for (int r = 0; r < RL; ++r) sbs[((size_t)t * 64 + lane) * RL + r] = hnew[r];
     }
-}
-
-// ---- LDS flags between the waves of a workgroup: relaxed accesses + explicit lgkmcnt waits.  (A
-// workgroup-scope release/acquire would also order global memory, i.e. put a vmcnt(0) drain of the
-// band stores back into the step loop.)
-typedef __attribute__((address_space(3))) uint32_t l_u32;
-__device__ __forceinline__ uint32_t lds_peek(uint32_t* p) {
-    const uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("" ::: "memory");   // data reads stay below the flag read
-    return v;
-}
-__device__ __forceinline__ void lds_post(uint32_t* p, uint32_t v) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS data accesses are done (LDS is in-order per wave)
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 #ifndef PWA_STEP_UNROLL

@@ -88,13 +88,16 @@ struct BatchKernelEntry {
     affine_kernel_t afn = nullptr;
     nwdist_kernel_t dfn = nullptr;
     batch_kernel_t fn_single = nullptr;   // every task a single strip: no hand-off accesses at all
+    batch_kernel_t fn_pair = nullptr;     // every task at most two strips: two waves per task, hand-off through an LDS ring
 };
 #define BK(R, M, S) {R, M, S, batch_scores_kernel<R, M, S, true>, "batch_scores_kernel<R=" #R "," #M "," #S ">", nullptr, nullptr, \
                      batch_scores_kernel<R, M, S, false>}
+#define BKP(R, M, S) {R, M, S, batch_scores_kernel<R, M, S, true>, "batch_scores_kernel<R=" #R "," #M "," #S ">", nullptr, nullptr, \
+                      batch_scores_kernel<R, M, S, false>, batch_scores_pair_kernel<R, M, S>}
 const BatchKernelEntry kBatchKernels[] = {
     BK(76, BM_SW, SC_PERM),   BK(104, BM_SW, SC_PERM),
-    BK(40, BM_SWS, SC_PERM),  BK(52, BM_SWS, SC_PERM),  BK(76, BM_SWS, SC_PERM),  BK(96, BM_SWS, SC_PERM),
-    BK(40, BM_SWS, SC_CMP),   BK(52, BM_SWS, SC_CMP),   BK(76, BM_SWS, SC_CMP),   BK(96, BM_SWS, SC_CMP),
+    BK(40, BM_SWS, SC_PERM),  BKP(52, BM_SWS, SC_PERM), BKP(76, BM_SWS, SC_PERM), BK(96, BM_SWS, SC_PERM),   // R=96 paired spills in the column loop
+    BK(40, BM_SWS, SC_CMP),   BKP(52, BM_SWS, SC_CMP),  BKP(76, BM_SWS, SC_CMP),  BKP(96, BM_SWS, SC_CMP),
     BK(64, BM_SW, SC_PERM),   BK(128, BM_SW, SC_PERM),  BK(152, BM_SW, SC_PERM),
     BK(64, BM_SW, SC_CMP),    BK(128, BM_SW, SC_CMP),   BK(152, BM_SW, SC_CMP),
     BK(64, BM_NW, SC_PERM),   BK(128, BM_NW, SC_PERM),  BK(152, BM_NW, SC_PERM),
@@ -110,6 +113,7 @@ const BatchKernelEntry kBatchKernels[] = {
 #undef DK
 };
 #undef BK
+#undef BKP
 
 const BatchKernelEntry* find_batch_kernel(int R, int mode, int score) {
     for (const auto& e : kBatchKernels)
@@ -249,7 +253,7 @@ struct pwa_batch {
     bool use_strips = false;
     const BatchKernelEntry* kern = nullptr;
     BatchParams bp{};
-    bool affine = false, nwdist = false, single_strip = false;
+    bool affine = false, nwdist = false, single_strip = false, paired = false;
     int32_t aff_go = 0, aff_ge = 0, aff_neg = 0;
     uint32_t grid = 0;
     DevBuf arena, tasks, slot_poff, slot_plen, slot_out, hand, queue, scores;
@@ -570,12 +574,14 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         std::vector<BatchTask> tasks(nt);
         std::vector<uint32_t> spoff(nt * 64, 0), splen(nt * 64, 0), sout(nt * 64, 0xffffffffu);
         uint32_t max_strips = 1;
+        size_t two_strip_tasks = 0;
         for (size_t t = 0; t < nt; ++t) {
             tasks[t].text_off = (uint32_t)aoff[ht[t].text];
             tasks[t].text_len = (uint32_t)slen(ht[t].text);
             tasks[t].slot0 = (uint32_t)(t * 64);
             tasks[t].n_strips = (uint32_t)((ht[t].maxlen + R - 1) / R);
             max_strips = std::max(max_strips, tasks[t].n_strips);
+            two_strip_tasks += tasks[t].n_strips == 2;
             for (uint32_t l = 0; l < ht[t].count; ++l) {
                 const uint32_t k = order[ht[t].first + l];
                 spoff[t * 64 + l] = (uint32_t)aoff[pair_a[k]];
@@ -593,14 +599,25 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         HIPC(ctx, hipMemcpy(b->slot_out.p, sout.data(), nt * 64 * 4, hipMemcpyHostToDevice));
 
         b->single_strip = !affine && !nwdist && max_strips == 1 && b->kern->fn_single != nullptr;
-        const void* kfn = b->single_strip ? reinterpret_cast<const void*>(b->kern->fn_single) : nwdist ? reinterpret_cast<const void*>(b->kern->dfn)
+        // Opt-in (PWA_PAIRED=1): two-strip tasks (the C3 shape: 150-row patterns in 76-row strips) as two waves of one
+        // workgroup that pass the boundary row through an LDS ring instead of HBM.  It removes the hand-off traffic
+        // (84 GB per C3 launch -> none) but couples the two waves' progress: [gpu] 172.5 ms against 161.9 ms for the
+        // HBM hand-off form, which already runs at the VALU issue limit -- hence not the default.
+        b->paired = false;
+        if (const char* e = std::getenv("PWA_PAIRED"))
+            b->paired = std::atoi(e) != 0 && !affine && !nwdist && max_strips == 2 && b->kern->fn_pair != nullptr &&
+                        two_strip_tasks * 8 >= nt * 7;   // at most 1 task in 8 may leave the second wave idle
+        const void* kfn = b->single_strip ? reinterpret_cast<const void*>(b->kern->fn_single)
+                          : b->paired     ? reinterpret_cast<const void*>(b->kern->fn_pair)
+                          : nwdist        ? reinterpret_cast<const void*>(b->kern->dfn)
                                  : (affine ? reinterpret_cast<const void*>(b->kern->afn) : reinterpret_cast<const void*>(b->kern->fn));
+        if (b->paired) b->kernel_name = std::string("batch_scores_pair_kernel") + (b->kernel_name.c_str() + std::strlen("batch_scores_kernel"));
         int per_cu = 0;
-        HIPC(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 64, 0));
+        HIPC(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, b->paired ? 128 : 64, 0));
         per_cu = std::max(1, std::min(per_cu, 32));
         b->grid = (uint32_t)std::min<uint64_t>(nt, (uint64_t)ctx->num_cu * per_cu);
         // int32 per half: one (affine: two) int4 per lane per 4-column block
-        const uint64_t half = ((max_strips > 1) ? ((max_m + 3) / 4 + 1) * 256 : 256) * ((affine || nwdist) ? 2 : 1);
+        const uint64_t half = ((max_strips > 1 && !b->paired) ? ((max_m + 3) / 4 + 1) * 256 : 256) * ((affine || nwdist) ? 2 : 1);
         HIPC(ctx, b->hand.alloc((size_t)b->grid * 2 * half * sizeof(int32_t)));
 
         BatchParams& P = b->bp;
@@ -732,7 +749,8 @@ int pwa_batch_run(pwa_batch* b, void* stream_v) {
                 ap.neg = b->aff_neg;
                 hipLaunchKernelGGL(b->kern->afn, dim3(b->grid), dim3(64), 0, st, ap);
             } else {
-                hipLaunchKernelGGL(b->single_strip ? b->kern->fn_single : b->kern->fn, dim3(b->grid), dim3(64), 0, st, b->bp);
+                if (b->paired) hipLaunchKernelGGL(b->kern->fn_pair, dim3(b->grid), dim3(128), 0, st, b->bp);
+                else hipLaunchKernelGGL(b->single_strip ? b->kern->fn_single : b->kern->fn, dim3(b->grid), dim3(64), 0, st, b->bp);
             }
             HIPC(ctx, hipGetLastError());
         } else {
@@ -801,6 +819,11 @@ int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint3
     if (!b->ran) return fail(ctx, PWA_E_INVALID, "pwa_batch_run has not been called");
     HIPC(ctx, hipEventSynchronize(b->ev1[(b->n_runs - 1) % pwa_batch::kRing]));
     if (b->use_strips || b->n_live == 0) {
+        if (b->paired && b->n_live) {   // the LDS hand-off spins are bounded; a wave that gave up says so here
+            uint32_t q[2] = {0, 0};
+            HIPC(ctx, hipMemcpy(q, b->queue.p, sizeof q, hipMemcpyDeviceToHost));
+            if (q[1] != 0) return fail(ctx, PWA_E_HIP, "strip hand-off timed out inside batch_scores_pair_kernel");
+        }
         HIPC(ctx, hipMemcpy(score_out, pwa_batch_d_scores(b), b->n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost));
         if (b->want_end) {   // only reachable with no live pairs
             if (end_i_out) std::memcpy(end_i_out, b->host_end_i.data(), b->n_pairs * 4);

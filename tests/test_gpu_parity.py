@@ -168,6 +168,39 @@ def test_scores_many_strips_and_long_texts(ctx):
             assert got == want, (mode, sc)
 
 
+def test_two_strip_tasks_through_the_lds_paired_kernel(ctx):
+    """opt-in form (PWA_PAIRED=1): local-alignment batches whose tasks have one or two strips run as two waves per task
+    with the strip boundary row in an LDS ring (batch_scores_pair_kernel): every text length residue mod 4, texts shorter than
+    one block, longer than the ring, a few single-strip tasks, ragged lanes, many more tasks than workgroups."""
+    rng = random.Random(4242)
+    txt_lens = [1, 2, 3, 4, 5, 6, 7, 61, 62, 63, 64, 65, 66, 67, 68, 69, 255, 256, 257, 1000, 1001, 1002, 1003]
+    txts = [O.gen(11, 1, i, m) for i, m in enumerate(txt_lens)]
+    for lo, hi, scoring, n_short in [(140, 152, (1, -1, -1), 2), (95, 104, (2, -3, -5), 1), (125, 150, (5, -4, -4), 0)]:
+        pats = [O.gen(11, 0, i, rng.randint(lo, hi)) for i in range(90)]
+        pats += [O.gen(11, 2, i, rng.randint(1, lo // 2)) for i in range(6)]
+        seqs = pats + txts
+        pa, pb = [], []
+        for j in range(len(txts)):
+            short_text = j < n_short   # a task made only of short patterns is a single strip
+            for i in range(len(pats)):
+                if (i >= 90) == short_text and rng.random() < 0.9:
+                    pa.append(i)
+                    pb.append(len(pats) + j)
+        os.environ["PWA_PAIRED"] = "1"   # opt-in form (read at batch creation)
+        try:
+            b = ctx.batch("sw", seqs, pa, pb, *scoring)
+        finally:
+            del os.environ["PWA_PAIRED"]
+        assert "pair_kernel" in b.info()["kernel"], b.info()
+        for _ in range(2):
+            b.run()
+            got = b.fetch()
+        b.close()
+        want = [O.score("sw", seqs[a], seqs[c], *scoring)[0] for a, c in zip(pa, pb)]
+        bad = [k for k in range(len(pa)) if got[k] != want[k]]
+        assert not bad, (scoring, bad[:5], [(len(seqs[pa[k]]), len(seqs[pb[k]]), got[k], want[k]) for k in bad[:5]])
+
+
 def test_batch_object_reuse(ctx, pkg):
     seqs = [O.gen(9, 0, i, 150) for i in range(130)] + [O.gen(9, 1, 0, 777)]
     pa = list(range(130))
