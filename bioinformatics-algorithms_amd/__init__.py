@@ -26,7 +26,7 @@ MODE = {"nw": 0, "sw": 1, "global": 0, "local": 1}
 EXPORTS = [
     "pwa_version", "pwa_strerror", "pwa_ctx_create", "pwa_ctx_destroy", "pwa_last_error", "pwa_ctx_set_score_band", "pwa_scores",
     "pwa_batch_create", "pwa_affine_batch_create", "pwa_scores_affine", "pwa_nwdist_batch_create", "pwa_distances", "pwa_upgma_newick", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_set_d_scores", "pwa_batch_fetch", "pwa_batch_info",
-    "pwa_batch_last_ms", "pwa_batch_run_times", "pwa_batch_destroy", "pwa_align", "pwa_align_matrices", "pwa_align_last_stats", "pwa_align_batch",
+    "pwa_batch_last_ms", "pwa_batch_run_times", "pwa_batch_destroy", "pwa_align", "pwa_align_matrices", "pwa_align_last_stats", "pwa_align_batch", "pwa_overlaps",
     "pwa_cigar_bound", "pwa_mdz_bound", "pwa_format_alignment", "pwa_alignment_overlap",
 ]
 
@@ -81,6 +81,7 @@ def lib():
     L.pwa_align_matrices.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_uint64, vp, C.c_uint64, vp, vp]
     L.pwa_align_last_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), u64p]
     L.pwa_align_batch.argtypes = batch_in + [i32p, vp, u64p, u64p, u64p, u64p]
+    L.pwa_overlaps.argtypes = batch_in + [i32p, i32p]
     L.pwa_cigar_bound.argtypes = [C.c_uint64]
     L.pwa_cigar_bound.restype = C.c_uint64
     L.pwa_mdz_bound.argtypes = [C.c_uint64]
@@ -279,6 +280,18 @@ class Context:
             res.append(dict(score=sc[k], ops=o, end=(endc[2 * k], endc[2 * k + 1]),
                             start=(startc[2 * k], startc[2 * k + 1])))
         return res
+
+    def overlaps(self, mode, seqs, pair_a, pair_b, match, mismatch, gap):
+        """(scores, overlaps) of full alignments without their op lists: the -g selection inputs (hw2.cpp:342-350)."""
+        blob, off, seqs = pack_sequences(seqs)
+        n = len(pair_a)
+        pa = (C.c_uint32 * max(n, 1))(*pair_a)
+        pb = (C.c_uint32 * max(n, 1))(*pair_b)
+        sc = (C.c_int32 * max(n, 1))()
+        ov = (C.c_int32 * max(n, 1))()
+        rc = self._L.pwa_overlaps(self._h, MODE[mode], match, mismatch, gap, blob, off, len(seqs), pa, pb, n, sc, ov)
+        self._check(rc, "pwa_overlaps")
+        return list(sc[:n]), list(ov[:n])
 
     def align_stats(self):
         f, t, b = C.c_float(0), C.c_float(0), C.c_uint64(0)

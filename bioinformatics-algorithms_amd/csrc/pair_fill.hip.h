@@ -46,7 +46,7 @@ struct PairResult {
     uint32_t start_i, start_j;
     uint32_t n_ops;
     uint32_t overflow;   // ops capacity exceeded
-    uint32_t pad;
+    int32_t overlap;     // WALK_OVERLAP: longest run of equal, gap-free columns (hw2.cpp:267-278)
 };
 
 struct StripeBest {       // per stripe task (SW)
@@ -396,12 +396,13 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
 // (global_load_lds, 1 KiB per instruction, no VGPR round trip); while the walk runs inside one
 // window the window before it is already in flight into the second LDS buffer.  The walk state
 // is wave-uniform and lives in SGPRs; the only per-op latency left is one ds_read_u8.
-template <int RL, bool LOCAL, bool WALK>
+enum { WALK_NONE = 0, WALK_OPS = 1, WALK_OVERLAP = 2 };   // end cells only / op list / overlap length, no op list
+template <int RL, bool LOCAL, int WALK>
 __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) {
     constexpr int WIN = 64;                        // steps per LDS window
     constexpr int STEP_BYTES = 64 * RL;
     constexpr int WB = WIN * STEP_BYTES;           // bytes per window (16 KiB for RL = 4)
-    __shared__ __attribute__((aligned(16))) uint8_t win[WALK ? 2 * WB : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t win[WALK != WALK_NONE ? 2 * WB : 16];
     const int lane = threadIdx.x;
     const uint32_t pid = blockIdx.x;
     if (pid >= G.n_pairs) return;
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         res->end_i = (uint32_t)i;
         res->end_j = (uint32_t)j;
     }
-    if (!WALK) return;
+    if (WALK == WALK_NONE) return;
     // LDS-DMA of window w of stripe s into buffer `buf`: 1 KiB per instruction.  A window may run past
     // the end of its stripe or of the band; the host pads the band allocation by one window.
     auto issue = [&](int buf, int s, int w) {
@@ -453,6 +454,12 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
     // emitted by the lanes in parallel; the first non-'d' code behind it is handled in the same
     // trip.  (Typical alignments are mostly diagonal moves, so a trip retires several ops for the
     // price of one LDS round trip.)
+    // WALK_OVERLAP additionally looks at the symbols under each run of diagonal moves and keeps the longest run
+    // of equal ones (hw2.cpp:267-278: a gap column or a mismatch ends a run); the op list is not written.
+    constexpr bool OPS = WALK == WALK_OPS, OVL = WALK == WALK_OVERLAP;
+    g_cu8* pat = (g_cu8*)P.pat;
+    g_cu8* txt = (g_cu8*)P.txt;
+    int run = 0, best_run = 0;   // wave-uniform
     uint32_t cnt = 0;
     int cb = 0, cur_s = -1, cur_w = -1, pre_s = -1, pre_w = -1;
     bool stopped = false;
@@ -486,20 +493,38 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         }
         const unsigned long long dm = __ballot(code == TB_DIAG);
         const int L = (~dm == 0ull) ? 64 : __builtin_ctzll(~dm);        // leading run of diagonal moves
-        if (lane < L) ops[cnt + lane] = 'M';                             // hw2.cpp:164-169 / 240-245
+        if (OPS && lane < L) ops[cnt + lane] = 'M';                      // hw2.cpp:164-169 / 240-245
+        if (OVL && L > 0) {
+            bool eq = false;
+            if (lane < L) eq = pat[ii - 1] == txt[jj - 1];
+            const unsigned long long em = __ballot(eq);                  // bit d: column (i-d, j-d) holds equal symbols
+            const unsigned long long full = (L == 64) ? ~0ull : ((1ull << L) - 1ull);
+            if (em == full) {
+                run += L;
+            } else {
+                best_run = max(best_run, run + (int)__builtin_ctzll(~em));   // the run coming in ends inside this trip
+                int k = 0;
+                for (unsigned long long x = em; x; x &= x >> 1) ++k;     // longest run of ones inside the trip
+                best_run = max(best_run, k);
+                run = L - 1 - (63 - (int)__builtin_clzll(~em & full));   // equal columns at the far end carry on
+            }
+            best_run = max(best_run, run);
+        }
         cnt += L;
         i -= L;
         j -= L;
         if (L < 64) {
             const int c2 = __builtin_amdgcn_readlane(code, L);
             if (c2 == TB_UP) {                                           // hw2.cpp:170-174 / 246-250
-                if (lane == 0) ops[cnt] = 'D';
+                if (OPS && lane == 0) ops[cnt] = 'D';
                 ++cnt;
                 --i;
+                run = 0;
             } else if (c2 == TB_LEFT) {                                  // hw2.cpp:175-179 / 251-255
-                if (lane == 0) ops[cnt] = 'I';
+                if (OPS && lane == 0) ops[cnt] = 'I';
                 ++cnt;
                 --j;
+                run = 0;
             } else if (LOCAL && c2 == TB_STOP) {                         // dp == 0, hw2.cpp:239
                 stopped = true;
                 break;
@@ -509,10 +534,12 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
     }
     if (!LOCAL) {
         // hw2.cpp:170-179 with j == 0 or i == 0: column 0 is all 'u', row 0 all 'l' (125-136)
-        for (int o = lane; o < i; o += 64) ops[cnt + o] = 'D';
+        if (OPS)
+            for (int o = lane; o < i; o += 64) ops[cnt + o] = 'D';
         cnt += i;
         i = 0;
-        for (int o = lane; o < j; o += 64) ops[cnt + o] = 'I';
+        if (OPS)
+            for (int o = lane; o < j; o += 64) ops[cnt + o] = 'I';
         cnt += j;
         j = 0;
     }
@@ -521,6 +548,7 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         res->start_i = (uint32_t)i;
         res->start_j = (uint32_t)j;
         res->n_ops = cnt;
+        res->overlap = best_run;
         res->overflow = cnt > P.ops_cap ? 1u : 0u;   // cannot happen: a walk has at most n + m ops
     }
 }

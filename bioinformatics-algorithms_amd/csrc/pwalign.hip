@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -149,11 +150,14 @@ pair_kernel_t pair_fill_fn(PairGeom g, bool local, bool tb, bool sband) {
     return g.w == 1 ? pair_fill_pick<4, 1>(local, tb, sband) : pair_fill_pick<4, 4>(local, tb, sband);
 }
 template <int RL>
-pair_kernel_t pair_tb_pick(bool local, bool walk) {
-    if (local) return walk ? pair_traceback_kernel<RL, true, true> : pair_traceback_kernel<RL, true, false>;
-    return walk ? pair_traceback_kernel<RL, false, true> : pair_traceback_kernel<RL, false, false>;
+pair_kernel_t pair_tb_pick(bool local, int walk) {   // walk: WALK_NONE / WALK_OPS / WALK_OVERLAP
+    if (local)
+        return walk == WALK_OPS ? pair_traceback_kernel<RL, true, WALK_OPS>
+               : walk == WALK_OVERLAP ? pair_traceback_kernel<RL, true, WALK_OVERLAP> : pair_traceback_kernel<RL, true, WALK_NONE>;
+    return walk == WALK_OPS ? pair_traceback_kernel<RL, false, WALK_OPS>
+           : walk == WALK_OVERLAP ? pair_traceback_kernel<RL, false, WALK_OVERLAP> : pair_traceback_kernel<RL, false, WALK_NONE>;
 }
-pair_kernel_t pair_tb_fn(PairGeom g, bool local, bool walk) {
+pair_kernel_t pair_tb_fn(PairGeom g, bool local, int walk) {
     return g.rl == 2 ? pair_tb_pick<2>(local, walk) : pair_tb_pick<4>(local, walk);
 }
 
@@ -221,7 +225,7 @@ struct PairLaunch {
         return PWA_OK;
     }
     // enqueue: zero the queue / progress words, fill, then the walk (or only the end-cell pick)
-    int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, bool walk, hipEvent_t after_fill, bool sband = false) {
+    int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, int walk, hipEvent_t after_fill, bool sband = false) {
         HIPC(ctx, hipMemsetAsync(queue.p, 0, 16, st));
         HIPC(ctx, hipMemsetAsync(progress.p, 0, progress.bytes, st));
         hipLaunchKernelGGL(pair_fill_fn(geom, local, tb, sband), dim3(grid), dim3(64 * (geom.w + 1)), 0, st, G);
@@ -880,13 +884,18 @@ int pwa_scores(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const u
 }
 
 // ------------------------------------------------------------------------- full alignments
-int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* seq_bytes,
-                    const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
-                    uint64_t n_pairs, int32_t* score_out, uint8_t* ops, const uint64_t* ops_off, uint64_t* n_ops,
-                    uint64_t* end_cells, uint64_t* start_cells) try {
+} // extern "C" (reopened below): the shared implementation has C++ linkage
+// Full alignments of a pair list.  With `ops` the op lists come back (pwa_align_batch); without, only the
+// per-pair scores and -- with `overlap_out` -- the overlap lengths computed by the walk itself (pwa_overlaps).
+static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* seq_bytes,
+                            const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
+                            uint64_t n_pairs, int32_t* score_out, uint8_t* ops, const uint64_t* ops_off, uint64_t* n_ops,
+                            uint64_t* end_cells, uint64_t* start_cells, int32_t* overlap_out) try {
     if (!ctx) return PWA_E_INVALID;
     if (mode != PWA_MODE_NW && mode != PWA_MODE_SW) return fail(ctx, PWA_E_INVALID, "unknown mode");
-    if (!seq_off || !score_out || !ops_off || !n_ops || (n_pairs && (!pair_a || !pair_b)))
+    const bool want_ops = ops != nullptr;
+    if (!seq_off || !score_out || (want_ops && (!ops_off || !n_ops)) || (!want_ops && !overlap_out) ||
+        (n_pairs && (!pair_a || !pair_b)))
         return fail(ctx, PWA_E_INVALID, "null input");
     if (n_pairs >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "more than 2^32-2 pairs in one batch");
     for (uint64_t k = 0; k < n_pairs; ++k)
@@ -896,6 +905,14 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
     auto slen = [&](uint32_t s) -> uint64_t { return seq_off[s + 1] - seq_off[s]; };
     ctx->fill_ms = ctx->tb_ms = 0.f;
     ctx->band_bytes = 0;
+    const bool dbg = std::getenv("PWA_DEBUG") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {   // PWA_DEBUG: host-side time between marks
+        if (!dbg) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[pwa] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
 
     // raw-byte arena of the used sequences
     std::vector<uint8_t> is_used(n_seq, 0);
@@ -916,6 +933,7 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
         HIPC(ctx, arena.alloc(arena_bytes));
         HIPC(ctx, hipMemcpy(arena.p, host_arena.data(), arena_bytes, hipMemcpyHostToDevice));
     }
+    mark("arena upload");
 
     uint64_t longest_n = 0;
     for (uint64_t k = 0; k < n_pairs; ++k) longest_n = std::max(longest_n, slen(pair_a[k]));
@@ -925,29 +943,48 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
     size_t free_b = 0, total_b = 0;
     HIPC(ctx, hipMemGetInfo(&free_b, &total_b));
     const uint64_t budget = std::max<uint64_t>((uint64_t)(free_b * 0.8), 64ull << 20);
-
-    uint64_t k0 = 0;
-    while (k0 < n_pairs) {
-        uint64_t k1 = k0, band = 0, opsb = 0, max_m = 0;
+    // A chunk's band is written once and read along one path per pair, so nothing is gained by a big one, and
+    // hipMalloc costs ~23 ms per GB [gpu]: chunks of <= 1 GiB of band (or one pair, whatever it needs), all
+    // using ONE allocation sized for the largest chunk.
+    const uint64_t chunk_target = std::min<uint64_t>(budget, 1ull << 30);
+    struct Chunk {
+        uint64_t k0, k1, band, opsb;
+    };
+    std::vector<Chunk> chunks;
+    uint64_t band_cap = 0, ops_cap_b = 0, nc_cap = 0;
+    for (uint64_t k0 = 0; k0 < n_pairs;) {
+        uint64_t k1 = k0, band = 0, opsb = 0;
         while (k1 < n_pairs) {
             const uint64_t n = slen(pair_a[k1]), m = slen(pair_b[k1]);
             if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
             const uint64_t need = (n && m) ? align_up(tb_band_bytes(n, m), 256) : 0;
-            if (k1 > k0 && (band + need) * (ctx->score_band ? 5 : 1) + opsb + n + m > budget) break;
+            if (k1 > k0 && (band + need) * (ctx->score_band ? 5 : 1) + opsb + n + m > chunk_target) break;
             band += need;
             opsb += align_up(n + m + 1, 16);
-            max_m = std::max(max_m, m);
             ++k1;
         }
-        const uint64_t nc = k1 - k0;
-        if (band + opsb > budget && nc == 1 && band + opsb > (uint64_t)(free_b * 0.97))
+        if (band * (ctx->score_band ? 5 : 1) + opsb > budget && band + opsb > (uint64_t)(free_b * 0.97))
             return fail(ctx, PWA_E_NOMEM, "traceback band of a single pair exceeds free HBM");
-        DevBuf d_band, d_sband, d_ops, d_res;
+        chunks.push_back({k0, k1, band, opsb});
+        band_cap = std::max(band_cap, band);
+        ops_cap_b = std::max(ops_cap_b, opsb);
+        nc_cap = std::max(nc_cap, k1 - k0);
+        k0 = k1;
+    }
+    DevBuf d_band, d_sband, d_ops, d_res;
+    if (!chunks.empty()) {
+        HIPC(ctx, d_band.alloc(band_cap + 32768));   // + one traceback window: the walk stages whole windows
+        if (ctx->score_band) HIPC(ctx, d_sband.alloc(band_cap * sizeof(int32_t)));
+        HIPC(ctx, d_ops.alloc(want_ops ? ops_cap_b : 16));
+        HIPC(ctx, d_res.alloc(nc_cap * sizeof(PairResult)));
+    }
+    mark("band / ops allocation");
+    std::vector<uint8_t> host_ops(want_ops ? ops_cap_b : 0);
+
+    for (const Chunk& ch : chunks) {
+        const uint64_t k0 = ch.k0, k1 = ch.k1, band = ch.band, opsb = ch.opsb;
+        const uint64_t nc = k1 - k0;
         PairLaunch pl;
-        HIPC(ctx, d_band.alloc(band + 32768));   // + one traceback window: the walk stages whole windows
-        if (ctx->score_band) HIPC(ctx, d_sband.alloc(band * sizeof(int32_t)));
-        HIPC(ctx, d_ops.alloc(opsb));
-        HIPC(ctx, d_res.alloc(nc * sizeof(PairResult)));
         std::vector<PairResult> res(nc);
         std::vector<PairDesc> pd;
         std::vector<uint64_t> ooff(nc);
@@ -966,7 +1003,7 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
                 d.tb = d_band.as<uint8_t>() + bo;
                 if (ctx->score_band) d.sband = d_sband.as<int32_t>() + bo;
                 d.res = d_res.as<PairResult>() + q;
-                d.ops = d_ops.as<uint8_t>() + oo;
+                d.ops = want_ops ? d_ops.as<uint8_t>() + oo : d_ops.as<uint8_t>();   // WALK_OVERLAP never writes ops
                 d.ops_cap = (uint32_t)std::min<uint64_t>(n + m, 0xffffffffu);
                 pd.push_back(d);
                 bo += align_up(tb_band_bytes(n, m), 256);
@@ -979,18 +1016,19 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
             oo += align_up(n + m + 1, 16);
         }
         HIPC(ctx, hipMemcpy(d_res.p, res.data(), nc * sizeof(PairResult), hipMemcpyHostToDevice));
+        mark("chunk descriptors");
         if (!pd.empty()) {
             int rc = pl.build(ctx, pd, match, mismatch, gap, geom);
             if (rc != PWA_OK) return rc;
-            const bool dbg = std::getenv("PWA_DEBUG") != nullptr;
+            mark("task list build + upload");
             if (dbg) std::fprintf(stderr, "[pwa] fill launch grid=%u pairs=%u tasks=%u band=%llu rows=%llu\n", pl.grid,
                                   pl.G.n_pairs, pl.G.n_tasks, (unsigned long long)band, (unsigned long long)pl.row_bytes);
             HIPC(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-            rc = pl.launch(ctx, ctx->stream, local, true, true, ctx->ev[1], ctx->score_band);
+            rc = pl.launch(ctx, ctx->stream, local, true, want_ops ? WALK_OPS : WALK_OVERLAP, ctx->ev[1], ctx->score_band);
             if (rc != PWA_OK) return rc;
             HIPC(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
             HIPC(ctx, hipStreamSynchronize(ctx->stream));
-            if (dbg) std::fprintf(stderr, "[pwa] fill + traceback done\n");
+            mark("fill + walk (device)");
             rc = pl.check(ctx);
             if (rc != PWA_OK) return rc;
             float a = 0, c = 0;
@@ -1000,38 +1038,61 @@ int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, co
             ctx->tb_ms += c;
         }
         HIPC(ctx, hipMemcpy(res.data(), d_res.p, nc * sizeof(PairResult), hipMemcpyDeviceToHost));
-        std::vector<uint8_t> host_ops(opsb);
-        HIPC(ctx, hipMemcpy(host_ops.data(), d_ops.p, opsb, hipMemcpyDeviceToHost));
+        if (want_ops) HIPC(ctx, hipMemcpy(host_ops.data(), d_ops.p, opsb, hipMemcpyDeviceToHost));
+        mark("results (+ ops) to host");
         for (uint64_t q = 0; q < nc; ++q) {
             const uint64_t k = k0 + q, n = slen(pair_a[k]), m = slen(pair_b[k]);
             uint64_t cnt = res[q].n_ops;
             if (!(n && m)) {
-                // one side empty: NW walks the boundary (hw2.cpp:170-179), SW emits nothing (239)
+                // one side empty: NW walks the boundary (hw2.cpp:170-179), SW emits nothing (239); no column
+                // without a gap, so the overlap is 0 (hw2.cpp:267-278)
                 cnt = local ? 0 : n + m;
-                for (uint64_t o = 0; o < cnt; ++o) ops[ops_off[k] + o] = n ? 'D' : 'I';
+                if (want_ops)
+                    for (uint64_t o = 0; o < cnt; ++o) ops[ops_off[k] + o] = n ? 'D' : 'I';
                 if (start_cells) start_cells[2 * k] = start_cells[2 * k + 1] = 0;
+                if (overlap_out) overlap_out[k] = 0;
             } else {
                 if (res[q].overflow) return fail(ctx, PWA_E_CAPACITY, "internal: traceback longer than n+m");
-                std::memcpy(ops + ops_off[k], host_ops.data() + ooff[q], cnt);
+                if (want_ops) std::memcpy(ops + ops_off[k], host_ops.data() + ooff[q], cnt);
                 if (start_cells) {
                     start_cells[2 * k] = res[q].start_i;
                     start_cells[2 * k + 1] = res[q].start_j;
                 }
+                if (overlap_out) overlap_out[k] = res[q].overlap;
             }
             score_out[k] = res[q].score;
-            n_ops[k] = cnt;
+            if (n_ops) n_ops[k] = cnt;
             if (end_cells) {
                 end_cells[2 * k] = res[q].end_i;
                 end_cells[2 * k + 1] = res[q].end_j;
             }
         }
-        k0 = k1;
+        mark("scatter to caller buffers");
     }
     return PWA_OK;
 } catch (const std::bad_alloc&) {
     return fail(ctx, PWA_E_NOMEM, "host allocation failed");
 } catch (...) {
     return fail(ctx, PWA_E_HIP, "unexpected C++ exception");   // nothing may propagate across the C ABI
+}
+
+extern "C" {
+
+int pwa_align_batch(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* seq_bytes,
+                    const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
+                    uint64_t n_pairs, int32_t* score_out, uint8_t* ops, const uint64_t* ops_off, uint64_t* n_ops,
+                    uint64_t* end_cells, uint64_t* start_cells) {
+    if (ctx && !ops) return fail(ctx, PWA_E_INVALID, "null input");
+    return align_batch_impl(ctx, mode, match, mismatch, gap, seq_bytes, seq_off, n_seq, pair_a, pair_b, n_pairs, score_out, ops,
+                            ops_off, n_ops, end_cells, start_cells, nullptr);
+}
+
+int pwa_overlaps(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* seq_bytes, const uint64_t* seq_off,
+                 uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b, uint64_t n_pairs, int32_t* score_out,
+                 int32_t* overlap_out) {
+    if (ctx && !overlap_out) return fail(ctx, PWA_E_INVALID, "null input");
+    return align_batch_impl(ctx, mode, match, mismatch, gap, seq_bytes, seq_off, n_seq, pair_a, pair_b, n_pairs, score_out, nullptr,
+                            nullptr, nullptr, nullptr, nullptr, overlap_out);
 }
 
 int pwa_align(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* pattern, uint64_t n,

@@ -11,7 +11,8 @@
 //   -l : the report needs only the best pair's strings and the best is chosen by score alone
 //        (352-356, strict '>': first best wins) => one scores-only pass over all pairs
 //        (pwa_scores) + ONE full alignment (pwa_align);
-//   -g : selection needs every pair's alignment (344) => pwa_align_batch over all pairs;
+//   -g : selection needs every pair's overlap length (344-350) => pwa_overlaps over all pairs (fill + traceback
+//        band + device walk that returns the overlap, no op lists) + ONE full alignment for the winner;
 //   neither flag: the reference computes and then writes an EMPTY file (379-393) => no GPU work.
 //
 // One extra, non-colliding option: --device N (HIP device ordinal, default 0).
@@ -149,45 +150,44 @@ int main(int argc, char* argv[]) {
         int rc = pwa_ctx_create(device, &ctx);
         if (rc != PWA_OK) return engine_error(nullptr, "opening the MI355X device (no CPU fallback exists)", rc);
 
-        if (global) {
-            std::vector<uint64_t> ops_off(np);
-            uint64_t tot = 0;
-            for (size_t i = 0; i < np; ++i) {
-                ops_off[i] = tot;
-                tot += patterns[i].size() + references[i].size();
+        // one full alignment through the engine, rebuilt into the report's strings (both modes print only the winner)
+        auto align_winner = [&](int mode, int32_t expect_score, int32_t expect_overlap) -> int {
+            const std::string& p = patterns[best_index];
+            const std::string& t = references[best_index];
+            std::vector<uint8_t> ops(p.size() + t.size() + 1);
+            uint64_t n_ops = 0, end[2] = {0, 0};
+            const int rc = pwa_align(ctx, mode, match, mismatch, gap, reinterpret_cast<const uint8_t*>(p.data()), p.size(),
+                                     reinterpret_cast<const uint8_t*>(t.data()), t.size(), &best_score_field, ops.data(),
+                                     p.size() + t.size(), &n_ops, end, nullptr);
+            if (rc != PWA_OK) return engine_error(ctx, "pwa_align", rc);
+            if (best_score_field != expect_score || !format(p, t, ops.data(), n_ops, end, best) ||
+                (expect_overlap >= 0 && best.overlap != expect_overlap)) {
+                std::cerr << "Error: inconsistent alignment for pair " << best_index << std::endl;
+                return 2;
             }
-            std::vector<uint8_t> ops(tot + 1);
-            std::vector<int32_t> scores(np);
-            std::vector<uint64_t> n_ops(np), ends(2 * np);
-            rc = pwa_align_batch(ctx, PWA_MODE_NW, match, mismatch, gap, bytes, off.data(), (uint32_t)(2 * np), pa.data(),
-                                 pb.data(), np, scores.data(), ops.data(), ops_off.data(), n_ops.data(), ends.data(), nullptr);
+            return 0;
+        };
+
+        if (global) {
+            // hw2.cpp:342-350 keeps only each pair's overlap length: the device walk returns it, no op list leaves
+            // the GPU (pwa_overlaps); the winner is then aligned once more for its strings
+            std::vector<int32_t> scores(np), overlaps(np);
+            rc = pwa_overlaps(ctx, PWA_MODE_NW, match, mismatch, gap, bytes, off.data(), (uint32_t)(2 * np), pa.data(), pb.data(),
+                              np, scores.data(), overlaps.data());
             if (rc != PWA_OK) {
-                const int e = engine_error(ctx, "pwa_align_batch", rc);
+                const int e = engine_error(ctx, "pwa_overlaps", rc);
                 pwa_ctx_destroy(ctx);
                 return e;
             }
             int best_overlap = -1000000;   // hw2.cpp:326
-            for (size_t i = 0; i < np; ++i) {   // hw2.cpp:342-350: first strictly larger overlap wins
-                int32_t ov = 0;
-                if (pwa_alignment_overlap(reinterpret_cast<const uint8_t*>(patterns[i].data()), patterns[i].size(),
-                                          reinterpret_cast<const uint8_t*>(references[i].data()), references[i].size(),
-                                          ops.data() + ops_off[i], n_ops[i], &ends[2 * i], &ov) != PWA_OK) {
-                    std::cerr << "Error: inconsistent traceback for pair " << i << std::endl;
-                    pwa_ctx_destroy(ctx);
-                    return 2;
-                }
-                if (ov > best_overlap) {
-                    best_overlap = ov;
+            for (size_t i = 0; i < np; ++i)   // hw2.cpp:342-350: first strictly larger overlap wins
+                if (overlaps[i] > best_overlap) {
+                    best_overlap = overlaps[i];
                     best_index = (int)i;
-                    best_score_field = scores[i];
                 }
-            }
-            // only the winner's strings are ever printed (hw2.cpp:379-385)
-            if (best_index >= 0 && !format(patterns[best_index], references[best_index], ops.data() + ops_off[best_index],
-                                           n_ops[best_index], &ends[2 * best_index], best)) {
-                std::cerr << "Error: inconsistent traceback for pair " << best_index << std::endl;
+            if (const int e = align_winner(PWA_MODE_NW, scores[best_index], best_overlap)) {
                 pwa_ctx_destroy(ctx);
-                return 2;
+                return e;
             }
         } else {
             std::vector<int32_t> scores(np);
@@ -204,22 +204,9 @@ int main(int argc, char* argv[]) {
                     best_val = scores[i];
                     best_index = (int)i;
                 }
-            const std::string& p = patterns[best_index];
-            const std::string& t = references[best_index];
-            std::vector<uint8_t> ops(p.size() + t.size() + 1);
-            uint64_t n_ops = 0, end[2] = {0, 0};
-            rc = pwa_align(ctx, PWA_MODE_SW, match, mismatch, gap, reinterpret_cast<const uint8_t*>(p.data()), p.size(),
-                           reinterpret_cast<const uint8_t*>(t.data()), t.size(), &best_score_field, ops.data(),
-                           p.size() + t.size(), &n_ops, end, nullptr);
-            if (rc != PWA_OK) {
-                const int e = engine_error(ctx, "pwa_align", rc);
+            if (const int e = align_winner(PWA_MODE_SW, scores[best_index], -1)) {
                 pwa_ctx_destroy(ctx);
                 return e;
-            }
-            if (best_score_field != scores[best_index] || !format(p, t, ops.data(), n_ops, end, best)) {
-                std::cerr << "Error: inconsistent alignment for pair " << best_index << std::endl;
-                pwa_ctx_destroy(ctx);
-                return 2;
             }
         }
         pwa_ctx_destroy(ctx);

@@ -183,6 +183,18 @@ int pwa_align_batch(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, co
                     uint64_t *end_cells /* 2*n_pairs or NULL */, uint64_t *start_cells /* 2*n_pairs or NULL */);
 
 /*
+ * The -g selection without the op lists: hw2.cpp:342-350 keeps, of every pair's global alignment, only
+ * overlapLongestExactMatch(alignedPattern, alignedReference) (hw2.cpp:267-278) and the score.  Same fill and
+ * traceback band as pwa_align_batch; the device walk looks at the symbols under each run of diagonal moves
+ * and returns the longest run of equal, gap-free columns -- no op list is written or copied back.  The
+ * caller then asks pwa_align for the ONE winning pair (first strictly larger overlap, hw2.cpp:346).
+ *   score_out[k]   : as pwa_align_batch;   overlap_out[k] : as pwa_alignment_overlap on that pair's walk
+ */
+int pwa_overlaps(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const uint8_t *seq_bytes,
+                 const uint64_t *seq_off, uint32_t n_seq, const uint32_t *pair_a, const uint32_t *pair_b, uint64_t n_pairs,
+                 int32_t *score_out, int32_t *overlap_out);
+
+/*
  * Host-side post-processing of one alignment (no GPU work): everything hw2.cpp derives from
  * the walk -- the gapped strings (hw2.cpp:164-184 / 240-259), prepareCigarString (59-78),
  * prepareMDZString (80-116) and overlapLongestExactMatch (267-278) -- so that the five fields

@@ -86,6 +86,47 @@ def test_align_batch_matches_oracle(ctx):
                 assert tuple(r["start"]) == tuple(want["start"])
 
 
+def _mutate(rng, s, rate):
+    out = bytearray()
+    for c in s:
+        r = rng.random()
+        if r < rate / 3:
+            continue                                   # deletion
+        if r < 2 * rate / 3:
+            out.append(rng.choice(b"ACGT"))            # insertion
+        out.append(rng.choice(b"ACGT") if r > 1 - rate / 3 else c)
+    return bytes(out)
+
+
+def test_device_overlaps_match_oracle(ctx, pkg):
+    """pwa_overlaps: overlapLongestExactMatch (hw2.cpp:267-278) computed by the device walk, with no op list, for
+    every pair -- random pairs (short runs), mutated copies (runs much longer than one 64-lane trip, runs crossing
+    traceback windows and stripes), identical sequences, empty sides; global and local walks."""
+    rng = random.Random(99)
+    seqs = [bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, 300))) for _ in range(24)]
+    base = [bytes(rng.choice(b"ACGT") for _ in range(n)) for n in (64, 65, 129, 500, 1000, 2500)]
+    seqs += base
+    seqs += [_mutate(rng, b, rate) for b in base for rate in (0.002, 0.02, 0.2)]
+    seqs += [b"", b"A", b"ACGT" * 40, b"ACGT" * 40 + b"T"]
+    n = len(seqs)
+    pa = [rng.randrange(n) for _ in range(150)] + [24 + i for i in range(6) for _ in range(4)] + [n - 2, n - 2, n - 4]
+    pb = [rng.randrange(n) for _ in range(150)] + [k for i in range(6) for k in (24 + i, 30 + 3 * i, 31 + 3 * i, 32 + 3 * i)] \
+        + [n - 2, n - 1, n - 3]
+    for mode in ("nw", "sw"):
+        for sc in [(1, -1, -1), (2, -3, -5)]:
+            scores, ovl = ctx.overlaps(mode, seqs, pa, pb, *sc)
+            for k in range(len(pa)):
+                want = O.align(mode, seqs[pa[k]], seqs[pb[k]], *sc)
+                assert scores[k] == want["score"], (mode, sc, k)
+                assert ovl[k] == want["overlap"], (mode, sc, k, len(seqs[pa[k]]), len(seqs[pb[k]]), ovl[k], want["overlap"])
+    # the same walk with op lists agrees with itself
+    res = ctx.align_batch("nw", seqs, pa, pb, 1, -1, -1)
+    scores, ovl = ctx.overlaps("nw", seqs, pa, pb, 1, -1, -1)
+    for k, r in enumerate(res):
+        assert r["score"] == scores[k]
+        assert pkg.alignment_overlap(seqs[pa[k]], seqs[pb[k]], r["ops"], r["end"]) == ovl[k]
+
+
 # ------------------------------------------------------------------ scores-only batches
 def test_scores_c3_small_fixture(ctx):
     c3 = load_golden("c3_small")
