@@ -943,10 +943,11 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     size_t free_b = 0, total_b = 0;
     HIPC(ctx, hipMemGetInfo(&free_b, &total_b));
     const uint64_t budget = std::max<uint64_t>((uint64_t)(free_b * 0.8), 64ull << 20);
-    // A chunk's band is written once and read along one path per pair, so nothing is gained by a big one, and
-    // hipMalloc costs ~23 ms per GB [gpu]: chunks of <= 1 GiB of band (or one pair, whatever it needs), all
-    // using ONE allocation sized for the largest chunk.
-    const uint64_t chunk_target = std::min<uint64_t>(budget, 1ull << 30);
+    // A chunk's band is written once and read along one path per pair, so nothing is gained by a huge one, while
+    // hipMalloc gets slow for very large requests ([gpu] profiles/r01_malloc_probe.txt: 0.3 ms up to 8 GiB,
+    // 0.24 s for 10.5 GB, >1 s for 16 GiB): chunks of <= 4 GiB of band (enough pairs to fill every CU; or one
+    // pair, whatever it needs), all using ONE allocation sized for the largest chunk.
+    const uint64_t chunk_target = std::min<uint64_t>(budget, 4ull << 30);
     struct Chunk {
         uint64_t k0, k1, band, opsb;
     };
