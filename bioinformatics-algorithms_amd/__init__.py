@@ -28,6 +28,7 @@ EXPORTS = [
     "pwa_batch_create", "pwa_affine_batch_create", "pwa_scores_affine", "pwa_nwdist_batch_create", "pwa_distances", "pwa_upgma_newick", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_set_d_scores", "pwa_batch_fetch", "pwa_batch_info",
     "pwa_batch_last_ms", "pwa_batch_run_times", "pwa_batch_destroy", "pwa_align", "pwa_align_matrices", "pwa_align_last_stats", "pwa_align_batch", "pwa_overlaps",
     "pwa_cigar_bound", "pwa_mdz_bound", "pwa_format_alignment", "pwa_alignment_overlap",
+    "pwa_fasta_read", "pwa_fasta_n_seq", "pwa_fasta_bytes", "pwa_fasta_offsets", "pwa_fasta_first_seq", "pwa_fasta_free",
 ]
 
 
@@ -88,6 +89,17 @@ def lib():
     L.pwa_mdz_bound.restype = C.c_uint64
     L.pwa_alignment_overlap.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, u64p, i32p]
     L.pwa_format_alignment.argtypes = [vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, u64p, vp, vp, vp, vp, i32p]
+    L.pwa_fasta_read.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_int)]
+    L.pwa_fasta_n_seq.argtypes = [vp]
+    L.pwa_fasta_n_seq.restype = C.c_uint32
+    L.pwa_fasta_bytes.argtypes = [vp]
+    L.pwa_fasta_bytes.restype = vp
+    L.pwa_fasta_offsets.argtypes = [vp]
+    L.pwa_fasta_offsets.restype = u64p
+    L.pwa_fasta_first_seq.argtypes = [vp]
+    L.pwa_fasta_first_seq.restype = u32p
+    L.pwa_fasta_free.argtypes = [vp]
+    L.pwa_fasta_free.restype = None
     _lib = L
     return L
 
@@ -106,6 +118,27 @@ def pack_sequences(seqs):
         tot += len(s)
     off[len(seqs)] = tot
     return b"".join(seqs), off, seqs
+
+
+def read_fasta(paths, n_threads=0):
+    """readFasta (hw2.cpp:25-57) over one or more files -> (blob, offsets, first_seq): sequence k is
+    blob[offsets[k]:offsets[k + 1]], the sequences of paths[i] are first_seq[i] .. first_seq[i + 1] - 1."""
+    L = lib()
+    if isinstance(paths, (str, bytes)):
+        paths = [paths]
+    arr = (C.c_char_p * max(len(paths), 1))(*[os.fsencode(p) for p in paths])
+    h, bad = C.c_void_p(), C.c_int(-1)
+    rc = L.pwa_fasta_read(arr, len(paths), n_threads, C.byref(h), C.byref(bad))
+    if rc != 0:
+        raise PwaError("pwa_fasta_read: %s (%s)" % (L.pwa_strerror(rc).decode(), paths[bad.value] if bad.value >= 0 else "-"))
+    try:
+        n = L.pwa_fasta_n_seq(h)
+        off = list(L.pwa_fasta_offsets(h)[:n + 1])
+        first = list(L.pwa_fasta_first_seq(h)[:len(paths) + 1])
+        blob = C.string_at(L.pwa_fasta_bytes(h), off[n]) if off[n] else b""
+    finally:
+        L.pwa_fasta_free(h)
+    return blob, off, first
 
 
 def alignment_overlap(pattern, text, ops, end):

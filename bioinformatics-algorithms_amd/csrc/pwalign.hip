@@ -288,6 +288,7 @@ const char* pwa_strerror(int code) {
         case PWA_E_HIP: return "HIP runtime error";
         case PWA_E_NOMEM: return "out of memory";
         case PWA_E_CAPACITY: return "capacity exceeded";
+        case PWA_E_IO: return "cannot open or read file";
         default: return "unknown error";
     }
 }

@@ -5,7 +5,8 @@
 // same argument handling (290-307), stderr texts and exit codes (281-284, 28-31, 319-322, 374-377),
 // and the same bytes in the output file (379-393).  The per-pair DP (hw2.cpp:328-338) is NOT done
 // here: it goes through the C ABI to the HIP kernels.  What stays on the host is what the survey
-// marks as host work: FASTA reading, CIGAR / MD:Z / overlap strings, best-pair selection, the report.
+// marks as host work: FASTA reading (pwa_fasta_read: the reference's semantics, parsed in parallel into the
+// engine's blob + offsets layout), CIGAR / MD:Z strings of the winner, best-pair selection, the report.
 //
 // Restructuring that keeps the output identical:
 //   -l : the report needs only the best pair's strings and the best is chosen by score alone
@@ -29,32 +30,6 @@
 #include "../../include/pwalign.h"
 
 namespace {
-
-// hw2.cpp:25-57: headers dropped, bodies concatenated, trailing whitespace / CR stripped,
-// blank lines skipped, records with an empty body dropped.
-bool read_fasta(const std::string& path, std::vector<std::string>& out) {
-    std::ifstream in(path.c_str(), std::ios::binary);
-    if (!in) return false;
-    std::string line, cur;
-    while (std::getline(in, line)) {
-        while (!line.empty()) {
-            const unsigned char c = (unsigned char)line.back();
-            if (c == '\r' || std::isspace(c)) line.pop_back();
-            else break;
-        }
-        if (line.empty()) continue;
-        if (line[0] == '>') {
-            if (!cur.empty()) {
-                out.push_back(cur);
-                cur.clear();
-            }
-        } else {
-            cur += line;
-        }
-    }
-    if (!cur.empty()) out.push_back(cur);
-    return true;
-}
 
 struct Formatted {
     std::string aligned_pattern, aligned_reference, cigar, mdz;
@@ -107,44 +82,44 @@ int main(int argc, char* argv[]) {
         } else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
     }
 
-    std::vector<std::string> patterns, references;
-    if (!read_fasta(pattern_file, patterns)) {   // hw2.cpp:28-31 (exit(1) inside readFasta)
-        std::cerr << "Error: Cannot open file " << pattern_file << std::endl;
-        return 1;
+    // readFasta (hw2.cpp:25-57) for both files: one blob + offsets, the layout the engine takes (pwa_fasta_read).
+    // The reference reads the pattern file first and exits at the first file it cannot open (28-31, 317-318).
+    pwa_fasta* fa = nullptr;
+    {
+        const char* paths[2] = {pattern_file.c_str(), reference_file.c_str()};
+        int bad = -1;
+        const int rc = pwa_fasta_read(paths, 2, 0, &fa, &bad);
+        if (rc == PWA_E_IO) {
+            std::cerr << "Error: Cannot open file " << (bad == 1 ? reference_file : pattern_file) << std::endl;
+            return 1;
+        }
+        if (rc != PWA_OK) return engine_error(nullptr, "reading the FASTA files", rc);
     }
-    if (!read_fasta(reference_file, references)) {
-        std::cerr << "Error: Cannot open file " << reference_file << std::endl;
-        return 1;
-    }
-    if (patterns.size() != references.size()) {   // hw2.cpp:319-322
+    struct FastaGuard {
+        pwa_fasta* f;
+        ~FastaGuard() { pwa_fasta_free(f); }
+    } fasta_guard{fa};
+    const uint32_t* first = pwa_fasta_first_seq(fa);
+    const uint64_t* off = pwa_fasta_offsets(fa);
+    const uint8_t* bytes = pwa_fasta_bytes(fa);
+    const size_t np = first[1] - first[0];
+    if (np != (size_t)(first[2] - first[1])) {   // hw2.cpp:319-322
         std::cerr << "Error: Number of patterns and references do not match." << std::endl;
         return 1;
     }
-    const size_t np = patterns.size();
+    // sequences: patterns 0..np-1, references np..2np-1; pair i = (i, np + i)   (hw2.cpp:328-338)
+    auto seq = [&](size_t k) { return std::string(reinterpret_cast<const char*>(bytes) + off[k], (size_t)(off[k + 1] - off[k])); };
 
     int best_index = -1;
     int32_t best_score_field = 0;
     Formatted best;
 
     if ((global || local) && np > 0) {
-        // sequences: patterns 0..np-1, references np..2np-1; pair i = (i, np + i)   (hw2.cpp:328-338)
-        std::vector<uint64_t> off(2 * np + 1, 0);
-        std::string blob;
-        for (size_t i = 0; i < np; ++i) {
-            off[i] = blob.size();
-            blob += patterns[i];
-        }
-        for (size_t i = 0; i < np; ++i) {
-            off[np + i] = blob.size();
-            blob += references[i];
-        }
-        off[2 * np] = blob.size();
         std::vector<uint32_t> pa(np), pb(np);
         for (size_t i = 0; i < np; ++i) {
             pa[i] = (uint32_t)i;
             pb[i] = (uint32_t)(np + i);
         }
-        const uint8_t* bytes = reinterpret_cast<const uint8_t*>(blob.data());
 
         pwa_ctx* ctx = nullptr;
         int rc = pwa_ctx_create(device, &ctx);
@@ -152,8 +127,7 @@ int main(int argc, char* argv[]) {
 
         // one full alignment through the engine, rebuilt into the report's strings (both modes print only the winner)
         auto align_winner = [&](int mode, int32_t expect_score, int32_t expect_overlap) -> int {
-            const std::string& p = patterns[best_index];
-            const std::string& t = references[best_index];
+            const std::string p = seq((size_t)best_index), t = seq(np + (size_t)best_index);
             std::vector<uint8_t> ops(p.size() + t.size() + 1);
             uint64_t n_ops = 0, end[2] = {0, 0};
             const int rc = pwa_align(ctx, mode, match, mismatch, gap, reinterpret_cast<const uint8_t*>(p.data()), p.size(),
@@ -172,7 +146,7 @@ int main(int argc, char* argv[]) {
             // hw2.cpp:342-350 keeps only each pair's overlap length: the device walk returns it, no op list leaves
             // the GPU (pwa_overlaps); the winner is then aligned once more for its strings
             std::vector<int32_t> scores(np), overlaps(np);
-            rc = pwa_overlaps(ctx, PWA_MODE_NW, match, mismatch, gap, bytes, off.data(), (uint32_t)(2 * np), pa.data(), pb.data(),
+            rc = pwa_overlaps(ctx, PWA_MODE_NW, match, mismatch, gap, bytes, off, (uint32_t)(2 * np), pa.data(), pb.data(),
                               np, scores.data(), overlaps.data());
             if (rc != PWA_OK) {
                 const int e = engine_error(ctx, "pwa_overlaps", rc);
@@ -191,7 +165,7 @@ int main(int argc, char* argv[]) {
             }
         } else {
             std::vector<int32_t> scores(np);
-            rc = pwa_scores(ctx, PWA_MODE_SW, match, mismatch, gap, bytes, off.data(), (uint32_t)(2 * np), pa.data(), pb.data(),
+            rc = pwa_scores(ctx, PWA_MODE_SW, match, mismatch, gap, bytes, off, (uint32_t)(2 * np), pa.data(), pb.data(),
                             np, scores.data(), nullptr, nullptr);
             if (rc != PWA_OK) {
                 const int e = engine_error(ctx, "pwa_scores", rc);
@@ -219,8 +193,8 @@ int main(int argc, char* argv[]) {
     }
     if ((global || local) && best_index >= 0) {   // hw2.cpp:379-393; both flags: global wins
         out << (global ? "Longest overlap:" : "Highest local alignment score:") << std::endl;
-        out << "pattern=" << patterns[best_index] << std::endl;
-        out << "reference=" << references[best_index] << std::endl;
+        out << "pattern=" << seq((size_t)best_index) << std::endl;
+        out << "reference=" << seq(np + (size_t)best_index) << std::endl;
         out << "Score =" << best_score_field << std::endl;
         out << "CIGAR =" << best.cigar << std::endl;
         out << "MD:Z=" << best.mdz << std::endl;

@@ -39,6 +39,7 @@ extern "C" {
 #define PWA_E_HIP (-3)         /* a HIP call failed (text in pwa_last_error)                     */
 #define PWA_E_NOMEM (-4)       /* host or device allocation failed                              */
 #define PWA_E_CAPACITY (-5)    /* caller buffer too small / problem exceeds an index width       */
+#define PWA_E_IO (-6)          /* a file cannot be opened or read (pwa_fasta_read)                */
 
 typedef struct pwa_ctx pwa_ctx;
 typedef struct pwa_batch pwa_batch;
@@ -193,6 +194,23 @@ int pwa_align_batch(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, co
 int pwa_overlaps(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const uint8_t *seq_bytes,
                  const uint64_t *seq_off, uint32_t n_seq, const uint32_t *pair_a, const uint32_t *pair_b, uint64_t n_pairs,
                  int32_t *score_out, int32_t *overlap_out);
+
+/*
+ * FASTA ingest (no GPU work): readFasta (hw2.cpp:25-57) on one or more files, straight into the layout the
+ * entries above consume -- ONE byte blob and n_seq + 1 offsets -- parsed by n_threads threads (<= 0: one per
+ * host core, at most 16) over the mmap'ed file.  Semantics are the reference's, byte for byte: header text is
+ * dropped, lines are joined after stripping trailing '\r' / whitespace, blank lines are skipped, records with an
+ * empty body are dropped, bytes ahead of the first header form a record.  Sequences of paths[i] are
+ * first_seq[i] .. first_seq[i + 1] - 1.  PWA_E_IO when a file cannot be opened (the reference prints
+ * "Error: Cannot open file <name>" and exits 1, hw2.cpp:28-31): *failed_path is its index.
+ */
+typedef struct pwa_fasta pwa_fasta;
+int pwa_fasta_read(const char *const *paths, int n_paths, int n_threads, pwa_fasta **out, int *failed_path /* or NULL */);
+uint32_t pwa_fasta_n_seq(const pwa_fasta *f);
+const uint8_t *pwa_fasta_bytes(const pwa_fasta *f);
+const uint64_t *pwa_fasta_offsets(const pwa_fasta *f);   /* n_seq + 1 */
+const uint32_t *pwa_fasta_first_seq(const pwa_fasta *f); /* n_paths + 1 */
+void pwa_fasta_free(pwa_fasta *f);
 
 /*
  * Host-side post-processing of one alignment (no GPU work): everything hw2.cpp derives from

@@ -58,4 +58,33 @@ void ref_free(ref_result* r) {
 }
 int ref_main(int argc, char** argv) { return hw2_reference_main(argc, argv); }
 
+// readFasta (hw2.cpp:25-57) -> one blob + count + 1 offsets.  The reference exit(1)s on a file it cannot
+// open (28-31): callers pass existing files only.
+struct ref_fasta {
+    size_t count;
+    char* blob;
+    size_t* off;
+};
+ref_fasta* ref_read_fasta(const char* path) {
+    const std::vector<std::string> v = readFasta(path);
+    ref_fasta* f = static_cast<ref_fasta*>(std::malloc(sizeof(ref_fasta)));
+    f->count = v.size();
+    f->off = static_cast<size_t*>(std::malloc((v.size() + 1) * sizeof(size_t)));
+    size_t tot = 0;
+    for (size_t i = 0; i < v.size(); ++i) {
+        f->off[i] = tot;
+        tot += v[i].size();
+    }
+    f->off[v.size()] = tot;
+    f->blob = static_cast<char*>(std::malloc(tot + 1));
+    for (size_t i = 0; i < v.size(); ++i) std::memcpy(f->blob + f->off[i], v[i].data(), v[i].size());
+    return f;
+}
+void ref_free_fasta(ref_fasta* f) {
+    if (!f) return;
+    std::free(f->blob);
+    std::free(f->off);
+    std::free(f);
+}
+
 }  // extern "C"

@@ -88,6 +88,10 @@ def oracle():
         lib.orc_gen.restype = None
         lib.orc_hw2_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
         lib.orc_hw2_main.restype = C.c_int
+        lib.orc_read_fasta.argtypes = [C.c_char_p, C.POINTER(_OrcFasta)]
+        lib.orc_read_fasta.restype = C.c_int
+        lib.orc_free_fasta.argtypes = [C.POINTER(_OrcFasta)]
+        lib.orc_free_fasta.restype = None
         _lib = lib
     return _lib
 
@@ -108,8 +112,41 @@ def ref():
         lib.ref_free.argtypes = [C.POINTER(_RefResult)]
         lib.ref_overlap.argtypes = [C.c_char_p, C.c_char_p]
         lib.ref_overlap.restype = C.c_int
+        lib.ref_read_fasta.argtypes = [C.c_char_p]
+        lib.ref_read_fasta.restype = C.POINTER(_RefFasta)
+        lib.ref_free_fasta.argtypes = [C.POINTER(_RefFasta)]
+        lib.ref_free_fasta.restype = None
         _ref = lib
     return _ref
+
+
+class _OrcFasta(C.Structure):   # oracle/hw2_oracle.h: orc_fasta
+    _fields_ = [("count", C.c_size_t), ("seq", C.POINTER(C.c_void_p)), ("len", C.POINTER(C.c_size_t))]
+
+
+class _RefFasta(C.Structure):   # oracle/ref_shim.cpp: ref_fasta
+    _fields_ = [("count", C.c_size_t), ("blob", C.c_void_p), ("off", C.POINTER(C.c_size_t))]
+
+
+def read_fasta(path):
+    """Oracle readFasta (hw2.cpp:25-57) -> list of bytes, or None when the file cannot be opened."""
+    lib = oracle()
+    f = _OrcFasta()
+    if lib.orc_read_fasta(os.fsencode(path), C.byref(f)) != 0:
+        return None
+    out = [C.string_at(f.seq[i], f.len[i]) for i in range(f.count)]
+    lib.orc_free_fasta(C.byref(f))
+    return out
+
+
+def ref_read_fasta(path):
+    """The compiled reference's readFasta; existing files only (it exit(1)s otherwise)."""
+    assert os.path.exists(path)
+    lib = ref()
+    f = lib.ref_read_fasta(os.fsencode(path)).contents
+    out = [C.string_at(f.blob + f.off[i], f.off[i + 1] - f.off[i]) for i in range(f.count)]
+    lib.ref_free_fasta(C.byref(f))
+    return out
 
 
 def _s(ptr):
