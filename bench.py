@@ -195,8 +195,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c2", "c2b", "c5", "hw3", "hw4", "g"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c2", "c2b", "c5", "hw3", "hw4", "g", "gb"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plen", type=int, default=150, help="pattern length of the g / gb workloads (150 = the C3 shape)")
     ap.add_argument("--small", action="store_true", help="reduced sizes (functional check only; line is marked invalid)")
     args = ap.parse_args()
 
@@ -220,7 +221,7 @@ def main():
     pkg = load_pkg()
     ctx = pkg.Context(local_rank)
 
-    if args.workload == "g":
+    if args.workload in ("g", "gb"):
         return bench_global_batch(args, pkg, ctx)
     if args.workload in ("c2", "c2b", "c5"):
         return bench_single_pair(args, pkg, ctx, rank, world, dist if use_dist else None, torch)
@@ -394,32 +395,37 @@ def bench_global_batch(args, pkg, ctx):
     """The `-g` shape: FULL alignments (fill + traceback band + walk) of many index-paired short patterns x long
     texts (hw2.cpp:328-338 with global = true), 1 GPU."""
     n_pairs = 256 if args.small else 4096
-    pats = [gen(1, 0, p, 150) for p in range(n_pairs)]
+    bands = args.workload == "gb"   # gb: Smith-Waterman with the int32 score band ALSO written (5 B/cell, SURVEY.md 8d)
+    mode = "sw" if bands else "nw"
+    ctx.set_score_band(bands)
+    plen = args.plen
+    pats = [gen(1, 0, p, plen) for p in range(n_pairs)]
     txts = [gen(1, 1, t, 10000) for t in range(256)]
     seqs = pats + txts
     pa = list(range(n_pairs))
     pb = [n_pairs + (k % 256) for k in range(n_pairs)]
     for _ in range(args.warmup):
-        ctx.align_batch("nw", seqs, pa, pb, 1, -1, -1)
+        ctx.align_batch(mode, seqs, pa, pb, 1, -1, -1)
     t0 = time.perf_counter()
     fill, tb = [], []
     for _ in range(args.steps):
-        res = ctx.align_batch("nw", seqs, pa, pb, 1, -1, -1)
+        res = ctx.align_batch(mode, seqs, pa, pb, 1, -1, -1)
         st = ctx.align_stats()
         fill.append(st["fill_ms"])
         tb.append(st["traceback_ms"])
     elapsed = time.perf_counter() - t0
-    cells = float(n_pairs) * 150 * 10000
+    cells = float(n_pairs) * plen * 10000
     st = ctx.align_stats()
     k_ms = float(np.mean(fill))
     line = {
-        "metric": "GCUPS (billion DP cells/s) NW full alignments of a pair batch (-g shape); bit-exact vs hw2.cpp",
+        "metric": "GCUPS (billion DP cells/s) %s full alignments of a pair batch (-g shape); bit-exact vs hw2.cpp" % mode.upper(),
         "value": cells * args.steps / elapsed / 1e9, "unit": "GCUPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "g: %d pairs 150 x 10000, NW fill + traceback band + walk, host buffers in and ops out" % n_pairs,
+        "config": {"workload": ("gb: %d pairs %d x 10000, SW fill writing int32 score band + traceback band (5 B/cell) + walk"
+                                if bands else "g: %d pairs %d x 10000, NW fill + traceback band + walk, host buffers in and ops out") % (n_pairs, plen),
                    "scoring": [1, -1, -1]},
-        "roofline": {"bound": "hbm", "kernel": "pair_fill_kernel<RL=2,W=4,NW,TB>", "achieved": st["band_bytes"] / (k_ms * 1e-3) / 1e9,
+        "roofline": {"bound": "hbm", "kernel": "pair_fill_kernel<RL=2,%s,TB%s>" % (mode.upper(), ",SBAND" if bands else ""), "achieved": st["band_bytes"] / (k_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st["band_bytes"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": None, "algorithmic_bytes_per_launch": st["band_bytes"], "kernel_ms": k_ms,
                      "traceback_ms": float(np.mean(tb)), "kernel_gcups": cells / (k_ms * 1e-3) / 1e9},

@@ -948,7 +948,8 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     // hipMalloc gets slow for very large requests ([gpu] profiles/r01_malloc_probe.txt: 0.3 ms up to 8 GiB,
     // 0.24 s for 10.5 GB, >1 s for 16 GiB): chunks of <= 4 GiB of band (enough pairs to fill every CU; or one
     // pair, whatever it needs), all using ONE allocation sized for the largest chunk.
-    const uint64_t chunk_target = std::min<uint64_t>(budget, 4ull << 30);
+    // (with the int32 score band on, that one is the large allocation: 2 GiB of codes + 8 GiB of scores)
+    const uint64_t chunk_target = std::min<uint64_t>(budget, ctx->score_band ? (10ull << 30) : (4ull << 30));
     struct Chunk {
         uint64_t k0, k1, band, opsb;
     };

@@ -86,6 +86,26 @@ def test_align_batch_matches_oracle(ctx):
                 assert tuple(r["start"]) == tuple(want["start"])
 
 
+def test_align_batch_with_score_band_matches_oracle(ctx):
+    """pwa_ctx_set_score_band: the fill also writes the int32 score band to HBM (5 B/cell, the reference's own
+    footprint, hw2.cpp:193-194); alignments must not change -- several chunks' worth of pairs, both modes."""
+    rng = random.Random(8)
+    seqs = [bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 300))) for _ in range(30)]
+    seqs += [O.gen(8, 1, 0, 3000), O.gen(8, 0, 0, 700)]
+    pa = [rng.randrange(32) for _ in range(80)] + [31]
+    pb = [rng.randrange(32) for _ in range(80)] + [30]
+    ctx.set_score_band(True)
+    try:
+        for mode in ("nw", "sw"):
+            res = ctx.align_batch(mode, seqs, pa, pb, 2, -3, -5)
+            for k, r in enumerate(res):
+                want = O.align(mode, seqs[pa[k]], seqs[pb[k]], 2, -3, -5)
+                assert (r["score"], r["ops"], tuple(r["end"]), tuple(r["start"])) == \
+                    (want["score"], want["ops"], tuple(want["end"]), tuple(want["start"])), (mode, k)
+    finally:
+        ctx.set_score_band(False)
+
+
 def _mutate(rng, s, rate):
     out = bytearray()
     for c in s:
