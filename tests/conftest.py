@@ -4,6 +4,15 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm bundles its own copy of the HIP runtime.  A process that uses both must load torch BEFORE
+# libpwalign.so (which pulls in /opt/rocm's): in the other order torch loads a second runtime and reports
+# "No HIP GPUs are available" ([gpu]: seen when test_gpu_parity.py ran on its own).  Importing it here makes the
+# suite independent of the collection order.
+try:
+    import torch  # noqa: F401
+except Exception:
+    torch = None
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 GOLDEN = os.path.join(HERE, "golden")
