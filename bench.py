@@ -43,6 +43,7 @@ VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 VALU_PER_CELL = {"SC_PERM": 10.75, "SC_CMP": 12.0,   # batch_nwdist_kernel<R,SCORE> (hw4)
                  "BM_AFFS,SC_PERM": 5.6, "BM_AFFS,SC_CMP": 7.6, "BM_AFF,SC_PERM": 7.6, "BM_AFF,SC_CMP": 9.6,
                  "BM_SWS,SC_PERM": 4.06, "BM_SWS,SC_CMP": 6.06,
+                 "BM_SWS,SC_PERM,LANES": 4.11, "BM_SWS,SC_CMP,LANES": 5.6,   # per-lane texts: 1248 / 1702 VALU per 304 cells (ISA)
                  "BM_SW,SC_PERM": 5.02, "BM_SW,SC_CMP": 6.9, "BM_NW,SC_PERM": 4.5, "BM_NW,SC_CMP": 6.5,
                  "BM_NWG,SC_PERM": 2.53, "BM_NWG,SC_CMP": 4.5}
 
@@ -157,6 +158,18 @@ def build_c3(rank, n_patterns=4096, n_texts=256, plen=150, tlen=10000):
     return "sw", seqs, pa, pb, (1, -1, -1), desc
 
 
+def build_c3i(rank, n_pairs=131072, plen=150, tlen=2000):
+    """Index-paired list, every pair its own text: the shape of the reference's own loop (hw2.cpp:328-338)."""
+    pats = [gen(1, 0, p, plen) for p in range(n_pairs)]
+    txts = [gen(1, 1, rank * n_pairs + t, tlen) for t in range(n_pairs)]
+    seqs = pats + txts
+    pa = np.arange(n_pairs, dtype=np.uint32)
+    pb = pa + np.uint32(n_pairs)
+    desc = {"workload": "c3i: SW scores-only, %d index-paired (pattern i, text i) pairs %d x %d bp per GPU, 1/-1/-1"
+                        % (n_pairs, plen, tlen), "pairs_per_gpu": int(n_pairs), "scoring": [1, -1, -1]}
+    return "sw", seqs, pa, pb, (1, -1, -1), desc
+
+
 def build_c4(rank, world, n_seq=1024, slen=1000):
     seqs = [gen(1, 2, i, slen) for i in range(n_seq)]
     ii, jj = np.triu_indices(n_seq, k=1)
@@ -195,7 +208,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c2", "c2b", "c5", "hw3", "hw4", "g", "gb"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c3i", "c4", "c2", "c2b", "c5", "hw3", "hw4", "g", "gb"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plen", type=int, default=150, help="pattern length of the g / gb workloads (150 = the C3 shape)")
     ap.add_argument("--small", action="store_true", help="reduced sizes (functional check only; line is marked invalid)")
@@ -229,6 +242,10 @@ def main():
     if args.workload == "c3":
         kw = dict(n_patterns=256, n_texts=16, tlen=2000) if args.small else {}
         mode, seqs, pa, pb, scoring, desc = build_c3(rank, **kw)
+        scaling = "weak"
+    elif args.workload == "c3i":
+        kw = dict(n_pairs=4096) if args.small else {}
+        mode, seqs, pa, pb, scoring, desc = build_c3i(rank, **kw)
         scaling = "weak"
     elif args.workload in ("hw3", "hw4"):
         kw = dict(n_seq=128) if args.small else {}
@@ -350,7 +367,7 @@ def main():
 
     line = {
         "metric": "GCUPS (billion DP cells/s) SW linear-gap, 1/2/4/8xMI355X; bit-exact vs hw2.cpp"
-                  if args.workload == "c3" else ("GCUPS (billion DP cells/s) affine-gap all-pairs score pass; bit-exact vs hw3.cpp"
+                  if args.workload in ("c3", "c3i") else ("GCUPS (billion DP cells/s) affine-gap all-pairs score pass; bit-exact vs hw3.cpp"
                                                  if args.workload == "hw3" else
                                                  "GCUPS (billion DP cells/s) NW + traceback-derived distance, all pairs; bit-exact vs hw4.cpp"
                                                  if args.workload == "hw4" else

@@ -53,6 +53,8 @@ struct BatchParams {
     const uint32_t* slot_poff;   // per slot: arena offset of the pattern
     const uint32_t* slot_plen;   // per slot: pattern length, 0 = empty lane
     const uint32_t* slot_out;    // per slot: index into scores
+    const uint32_t* slot_toff;   // LANES kernels (every lane its own text): per slot arena offset / length of the text
+    const uint32_t* slot_tlen;
     int32_t* scores;
     int32_t* hand;               // strip hand-off rows, one region per workgroup
     uint64_t hand_stride;        // int32 elements per workgroup region (2 halves)
@@ -62,6 +64,7 @@ struct BatchParams {
     int32_t match, mismatch, gap;
     uint32_t tab_hi, tab_lo;     // SC_PERM: byte table, selector 0 -> match, 1..7 -> mismatch
     uint32_t pad_word;           // symbol that matches nothing in any text, x4
+    uint32_t tpad_word;          // LANES: symbol that matches nothing in any pattern and differs from pad_word, x4
 };
 
 __device__ __forceinline__ int addw(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
@@ -152,8 +155,16 @@ constexpr int strip_waves_per_simd(int R, int MODE) {
 // MULTI = false: every task of the launch is a single strip -- the hand-off row accesses are compiled out
 // (with them, each wave parks an unconditional 1 KiB load + store per 4 columns on an L2-resident dummy
 // block: harmless for speed, but it shows up as ~45 MB of HBM traffic per C3 launch).
-template <int R, int MODE, int SCORE, bool MULTI>
+//
+// LANES = true (local alignment only): the 64 pairs of a task do not share a text -- the shape of the reference's
+// own loop, pattern i against reference i (hw2.cpp:328-338).  Every lane streams its own text (one dword per
+// 4-column block, prefetched a block ahead), the symbol splat moves from the scalar unit to four v_perm_b32, and
+// columns past a lane's own text are fed the symbol that matches nothing: local scores can then only decay, so
+// the lane's maximum is already final (the same argument that pads short patterns).  ~+3 % VALU per cell
+// against the shared-text form, against up to 64x fewer idle lanes on index-paired lists.
+template <int R, int MODE, int SCORE, bool MULTI, bool LANES = false>
 __global__ __launch_bounds__(64, strip_waves_per_simd(R, MODE)) void batch_scores_kernel(const BatchParams P) {
+    static_assert(!LANES || MODE == BM_SWS || MODE == BM_SW, "per-lane texts: local alignment only");
     constexpr int Q = R / 4;
     const int lane = threadIdx.x;
     int32_t* const hand = P.hand + (size_t)blockIdx.x * P.hand_stride;
@@ -178,7 +189,22 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R, MODE)) void batch_score
         const uint32_t poff = P.slot_poff[slot];
         const int n = (int)P.slot_plen[slot];
         const uint32_t outi = P.slot_out[slot];
-        const int nblk = m >> 2, rem = m & 3;
+        // LANES: task.text_len is the longest text of the task; all columns run as full, masked blocks
+        const int nblk = LANES ? (m + 3) >> 2 : m >> 2, rem = LANES ? 0 : m & 3;
+        const uint32_t* txl = tx;
+        int ml = m, last_dw = 0;
+        if (LANES) {
+            txl = reinterpret_cast<const uint32_t*>(P.arena + P.slot_toff[slot]);
+            ml = (int)P.slot_tlen[slot];
+            last_dw = ml > 0 ? (ml - 1) >> 2 : 0;   // loads never leave the lane's own text (+ arena slack)
+        }
+        // the lane's text word for block jb, symbols past the text replaced by the pad symbol
+        auto lane_word = [&](int jb) -> uint32_t {
+            const uint32_t w = txl[min(jb, last_dw)];
+            const int valid = ml - 4 * jb;
+            const uint32_t keep = valid >= 4 ? 0xffffffffu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
+            return (w & keep) | (P.tpad_word & ~keep);
+        };
 
         int best = 0;
         int nw_score = 0;
@@ -215,7 +241,7 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R, MODE)) void batch_score
             int4* hout4 = reinterpret_cast<int4*>(hout) + lane;
             int4 tnext = make_int4(0, 0, 0, 0);
             if (MULTI) tnext = hin4[0];
-            uint32_t cwn = tx[0];
+            uint32_t cwn = LANES ? lane_word(0) : tx[0];
             // single-strip form: row 0 is 0, but as a literal it makes hipcc split the first row's v_max3_i32 into
             // unsigned/signed v_max pairs that no longer fuse (+0.7 VALU per cell, [asm]); keep the zero opaque
             int zero = 0;
@@ -223,14 +249,18 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R, MODE)) void batch_score
             for (int jb = 0; jb < nblk; ++jb) {
                 const uint32_t cw = cwn;
                 const int4 tcur = tnext;
-                cwn = tx[jb + 1];   // arena slack makes the over-read safe
+                cwn = LANES ? lane_word(jb + 1) : tx[jb + 1];   // arena slack makes the over-read safe
                 if (MULTI) tnext = hin4[(size_t)(jb + 1) * in_stride];
                 int top[4], bot[4];
                 uint32_t cs[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const uint32_t c = (cw >> (8 * k)) & 0xffu;
-                    cs[k] = (SCORE == SC_PERM) ? c * 0x01010101u : c;
+                    if (LANES && SCORE == SC_PERM) {
+                        cs[k] = __builtin_amdgcn_perm(cw, cw, 0x01010101u * (uint32_t)k);   // byte k in all four bytes
+                    } else {
+                        const uint32_t c = (cw >> (8 * k)) & 0xffu;
+                        cs[k] = (SCORE == SC_PERM) ? c * 0x01010101u : c;
+                    }
                 }
                 {
                     const int tl[4] = {tcur.x, tcur.y, tcur.z, tcur.w};

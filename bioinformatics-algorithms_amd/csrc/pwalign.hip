@@ -59,6 +59,34 @@ struct DevBuf {   // RAII device allocation
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Stable LSD radix sort of `idx` by 64-bit keys (16-bit digits; passes whose digit is constant are skipped).
+// Sorting a million pairs with std::sort and a comparator that looks lengths up cost ~95 ms per batch [gpu box].
+void radix_sort_by_key(std::vector<uint64_t>& key, std::vector<uint32_t>& idx) {
+    const size_t n = idx.size();
+    std::vector<uint64_t> key2(n);
+    std::vector<uint32_t> idx2(n);
+    std::vector<size_t> cnt(65536);
+    for (int pass = 0; pass < 4; ++pass) {
+        const int sh = 16 * pass;
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (size_t i = 0; i < n; ++i) ++cnt[(key[i] >> sh) & 0xffff];
+        if (n && cnt[(key[0] >> sh) & 0xffff] == n) continue;
+        size_t run = 0;
+        for (size_t d = 0; d < 65536; ++d) {
+            const size_t c = cnt[d];
+            cnt[d] = run;
+            run += c;
+        }
+        for (size_t i = 0; i < n; ++i) {
+            const size_t o = cnt[(key[i] >> sh) & 0xffff]++;
+            key2[o] = key[i];
+            idx2[o] = idx[i];
+        }
+        key.swap(key2);
+        idx.swap(idx2);
+    }
+}
+
 int fail(pwa_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
     return code;
@@ -90,15 +118,21 @@ struct BatchKernelEntry {
     nwdist_kernel_t dfn = nullptr;
     batch_kernel_t fn_single = nullptr;   // every task a single strip: no hand-off accesses at all
     batch_kernel_t fn_pair = nullptr;     // every task at most two strips: two waves per task, hand-off through an LDS ring
+    batch_kernel_t fn_lanes = nullptr;         // every lane its own text (index-paired lists), multi-strip
+    batch_kernel_t fn_lanes_single = nullptr;  // ... every task a single strip
 };
 #define BK(R, M, S) {R, M, S, batch_scores_kernel<R, M, S, true>, "batch_scores_kernel<R=" #R "," #M "," #S ">", nullptr, nullptr, \
                      batch_scores_kernel<R, M, S, false>}
 #define BKP(R, M, S) {R, M, S, batch_scores_kernel<R, M, S, true>, "batch_scores_kernel<R=" #R "," #M "," #S ">", nullptr, nullptr, \
-                      batch_scores_kernel<R, M, S, false>, batch_scores_pair_kernel<R, M, S>}
+                      batch_scores_kernel<R, M, S, false>, batch_scores_pair_kernel<R, M, S>, \
+                      batch_scores_kernel<R, M, S, true, true>, batch_scores_kernel<R, M, S, false, true>}
+#define BKL(R, M, S) {R, M, S, batch_scores_kernel<R, M, S, true>, "batch_scores_kernel<R=" #R "," #M "," #S ">", nullptr, nullptr, \
+                      batch_scores_kernel<R, M, S, false>, nullptr, \
+                      batch_scores_kernel<R, M, S, true, true>, batch_scores_kernel<R, M, S, false, true>}
 const BatchKernelEntry kBatchKernels[] = {
     BK(76, BM_SW, SC_PERM),   BK(104, BM_SW, SC_PERM),
-    BK(40, BM_SWS, SC_PERM),  BKP(52, BM_SWS, SC_PERM), BKP(76, BM_SWS, SC_PERM), BK(96, BM_SWS, SC_PERM),   // R=96 paired spills in the column loop
-    BK(40, BM_SWS, SC_CMP),   BKP(52, BM_SWS, SC_CMP),  BKP(76, BM_SWS, SC_CMP),  BKP(96, BM_SWS, SC_CMP),
+    BKL(40, BM_SWS, SC_PERM), BKP(52, BM_SWS, SC_PERM), BKP(76, BM_SWS, SC_PERM), BKL(96, BM_SWS, SC_PERM),   // R=96 paired spills in the column loop
+    BKL(40, BM_SWS, SC_CMP),  BKP(52, BM_SWS, SC_CMP),  BKP(76, BM_SWS, SC_CMP),  BKP(96, BM_SWS, SC_CMP),
     BK(64, BM_SW, SC_PERM),   BK(128, BM_SW, SC_PERM),  BK(152, BM_SW, SC_PERM),
     BK(64, BM_SW, SC_CMP),    BK(128, BM_SW, SC_CMP),   BK(152, BM_SW, SC_CMP),
     BK(64, BM_NW, SC_PERM),   BK(128, BM_NW, SC_PERM),  BK(152, BM_NW, SC_PERM),
@@ -115,6 +149,7 @@ const BatchKernelEntry kBatchKernels[] = {
 };
 #undef BK
 #undef BKP
+#undef BKL
 
 const BatchKernelEntry* find_batch_kernel(int R, int mode, int score) {
     for (const auto& e : kBatchKernels)
@@ -257,10 +292,10 @@ struct pwa_batch {
     bool use_strips = false;
     const BatchKernelEntry* kern = nullptr;
     BatchParams bp{};
-    bool affine = false, nwdist = false, single_strip = false, paired = false;
+    bool affine = false, nwdist = false, single_strip = false, paired = false, lanes = false;
     int32_t aff_go = 0, aff_ge = 0, aff_neg = 0;
     uint32_t grid = 0;
-    DevBuf arena, tasks, slot_poff, slot_plen, slot_out, hand, queue, scores;
+    DevBuf arena, tasks, slot_poff, slot_plen, slot_out, slot_toff, slot_tlen, hand, queue, scores;
     // engine 2: wavefront kernels without traceback band (exact end cells, any scoring)
     PairLaunch pl;
     DevBuf pair_res;
@@ -356,6 +391,14 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
     for (uint64_t k = 0; k < n_pairs; ++k)
         if (pair_a[k] >= n_seq || pair_b[k] >= n_seq) return fail(ctx, PWA_E_INVALID, "pair index out of range");
     HIPC(ctx, hipSetDevice(ctx->device));
+    const bool dbg = std::getenv("PWA_DEBUG") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {   // PWA_DEBUG: host-side time between marks
+        if (!dbg) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[pwa] create: %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
 
     pwa_batch* b = new (std::nothrow) pwa_batch();
     if (!b) return fail(ctx, PWA_E_NOMEM, "host allocation");
@@ -437,6 +480,20 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         }
     }
 
+    // LANES kernels also pad TEXTS (columns past a lane's own text): that symbol must match no pattern symbol and
+    // must differ from the pattern pad, or padded rows would "match" padded columns.
+    int text_pad_byte = -1;   // raw-byte (SC_CMP) form; the coded (SC_PERM) form uses code 6 when the alphabet leaves it free
+    {
+        bool in_pattern[256] = {false};
+        std::vector<uint8_t> is_pat(n_seq, 0);
+        for (uint64_t k = 0; k < n_pairs; ++k) is_pat[pair_a[k]] = 1;
+        for (uint32_t s = 0; s < n_seq; ++s)
+            if (is_pat[s])
+                for (uint64_t o = seq_off[s]; o < seq_off[s + 1]; ++o) in_pattern[seq_bytes[o]] = true;
+        for (int v = 255; v >= 0 && text_pad_byte < 0; --v)
+            if (!in_pattern[v] && v != absent_byte) text_pad_byte = v;
+    }
+
     // ---- engine choice.  The strip engine pads short patterns with rows that match nothing; for SW
     // those rows can only hold values <= real rows if mismatch <= 0 and gap <= 0.
     const bool strips_ok = affine || nwdist || (!b->want_end && (!local || (mismatch <= 0 && gap <= 0)));
@@ -515,26 +572,58 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         HIPC(ctx, hipMemcpy(b->arena.p, host_arena.data(), arena_bytes, hipMemcpyHostToDevice));
     }
 
+    mark("validate + arena upload");
     if (b->use_strips) {
         // ---- wave tasks: pairs grouped by text, patterns sorted by length, 64 per wave
-        std::vector<uint32_t> order(live);
-        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-            if (pair_b[x] != pair_b[y]) return pair_b[x] < pair_b[y];
-            const uint64_t lx = slen(pair_a[x]), ly = slen(pair_a[y]);
-            if (lx != ly) return lx > ly;
-            return x < y;
-        });
+        std::vector<uint32_t> order(live);   // ascending pair index: the stable sorts below keep it as the last key
+        {
+            std::vector<uint64_t> key(order.size());   // text ascending, pattern length descending (lengths < 2^31)
+            for (size_t o = 0; o < order.size(); ++o)
+                key[o] = ((uint64_t)pair_b[order[o]] << 32) | (uint64_t)(0x7fffffffu - (uint32_t)slen(pair_a[order[o]]));
+            radix_sort_by_key(key, order);
+        }
         struct HostTask {
             uint32_t text, first, count;
-            uint64_t maxlen;
+            uint64_t maxlen;   // longest pattern of the task
+            uint64_t m;        // text length (LANES: the longest text of the task)
         };
         std::vector<HostTask> ht;
         for (size_t p = 0; p < order.size();) {
             size_t q = p;
             while (q < order.size() && q - p < 64 && pair_b[order[q]] == pair_b[order[p]]) ++q;
-            ht.push_back({pair_b[order[p]], (uint32_t)p, (uint32_t)(q - p), slen(pair_a[order[p]])});
+            ht.push_back({pair_b[order[p]], (uint32_t)p, (uint32_t)(q - p), slen(pair_a[order[p]]), slen(pair_b[order[p]])});
             p = q;
         }
+        // ---- lists whose pairs share few texts (the reference's own loop pairs pattern i with reference i,
+        // hw2.cpp:328-338) would leave most lanes of a text-grouped wave empty: give every lane its own text
+        // instead (LANES kernels, local alignment only).  Pairs are sorted so that a wave's 64 pairs need about
+        // the same number of strips and columns; a wave runs max(strips) x max(columns) of its lanes.
+        bool kernels_have_lanes = false;
+        for (const auto& e : kBatchKernels) kernels_have_lanes |= (e.fn_lanes != nullptr && e.score == score_path);
+        const bool text_pad_ok = score_path == SC_PERM ? n_alpha <= 6 : text_pad_byte >= 0;
+        b->lanes = kmode == BM_SW && !affine && !nwdist && kernels_have_lanes && text_pad_ok &&
+                   ht.size() * 64 > order.size() * 3 / 2 + 64 && !std::getenv("PWA_PAIRED");   // (the opt-in experiment wins)
+        if (const char* e = std::getenv("PWA_FORCE_LANES")) b->lanes = b->lanes && std::atoi(e) != 0;   // experiments only
+        if (b->lanes) {
+            order = live;
+            std::vector<uint64_t> key(order.size());   // nominal strips descending, then text length descending
+            for (size_t o = 0; o < order.size(); ++o) {
+                const uint64_t strips = (slen(pair_a[order[o]]) + 75) / 76;
+                key[o] = ((0x7fffffffull - strips) << 32) | (uint64_t)(0x7fffffffu - (uint32_t)slen(pair_b[order[o]]));
+            }
+            radix_sort_by_key(key, order);
+            ht.clear();
+            for (size_t p = 0; p < order.size(); p += 64) {
+                const size_t q = std::min(order.size(), p + 64);
+                uint64_t mn = 0, mm = 0;
+                for (size_t o = p; o < q; ++o) {
+                    mn = std::max(mn, slen(pair_a[order[o]]));
+                    mm = std::max(mm, slen(pair_b[order[o]]));
+                }
+                ht.push_back({pair_b[order[p]], (uint32_t)p, (uint32_t)(q - p), mn, mm});
+            }
+        }
+        mark("sort + group pairs");
         // ---- strip height: least padded work, ties to the taller strip
         int bestR = 0, best_mode = kmode;
         long double best_cost = -1;
@@ -544,6 +633,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             // SW has two forms: BM_SW (R registers per lane, 5.0 VALU per cell) and BM_SWS (2R registers, 4.06)
             const bool mode_ok = e.mode == kmode || (kmode == BM_SW && e.mode == BM_SWS);
             if (!mode_ok || e.score != score_path) continue;
+            if (b->lanes && !e.fn_lanes) continue;
             const int R = e.R;
             if (force && std::atoi(force) != R) continue;
             if (force_mode && std::atoi(force_mode) != e.mode) continue;
@@ -553,7 +643,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             long double cost = 0;
             for (const auto& t : ht) {
                 const uint64_t strips = (t.maxlen + R - 1) / R;
-                cost += (long double)(strips * R + 2 * (strips - 1)) * (long double)slen(t.text) * 64.0L;
+                cost += (long double)(strips * R + 2 * (strips - 1)) * (long double)t.m * 64.0L;
             }
             cost *= w;
             if (best_cost < 0 || cost < best_cost || (cost == best_cost && R > bestR)) {
@@ -566,23 +656,24 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         if (bestR == 0) return fail(ctx, PWA_E_INVALID, "internal: no kernel instantiation");
         const int R = bestR;
         b->padded_cells = 0;
-        for (const auto& t : ht) b->padded_cells += (t.maxlen + bestR - 1) / bestR * bestR * slen(t.text) * 64;
+        for (const auto& t : ht) b->padded_cells += (t.maxlen + bestR - 1) / bestR * bestR * (b->lanes ? (t.m + 3) / 4 * 4 : t.m) * 64;
         b->kern = find_batch_kernel(R, kmode, score_path);
         if (!b->kern) return fail(ctx, PWA_E_INVALID, "internal: no kernel instantiation");
         b->kernel_name = b->kern->name;
         std::sort(ht.begin(), ht.end(), [&](const HostTask& x, const HostTask& y) {   // longest first
-            const uint64_t cx = (x.maxlen + R - 1) / R * slen(x.text), cy = (y.maxlen + R - 1) / R * slen(y.text);
+            const uint64_t cx = (x.maxlen + R - 1) / R * x.m, cy = (y.maxlen + R - 1) / R * y.m;
             if (cx != cy) return cx > cy;
             return x.first < y.first;
         });
         const size_t nt = ht.size();
         std::vector<BatchTask> tasks(nt);
         std::vector<uint32_t> spoff(nt * 64, 0), splen(nt * 64, 0), sout(nt * 64, 0xffffffffu);
+        std::vector<uint32_t> stoff(b->lanes ? nt * 64 : 0, 0), stlen(b->lanes ? nt * 64 : 0, 0);   // empty lanes: no text, no pattern
         uint32_t max_strips = 1;
         size_t two_strip_tasks = 0;
         for (size_t t = 0; t < nt; ++t) {
             tasks[t].text_off = (uint32_t)aoff[ht[t].text];
-            tasks[t].text_len = (uint32_t)slen(ht[t].text);
+            tasks[t].text_len = (uint32_t)ht[t].m;
             tasks[t].slot0 = (uint32_t)(t * 64);
             tasks[t].n_strips = (uint32_t)((ht[t].maxlen + R - 1) / R);
             max_strips = std::max(max_strips, tasks[t].n_strips);
@@ -592,8 +683,19 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
                 spoff[t * 64 + l] = (uint32_t)aoff[pair_a[k]];
                 splen[t * 64 + l] = (uint32_t)slen(pair_a[k]);
                 sout[t * 64 + l] = k;
+                if (b->lanes) {
+                    stoff[t * 64 + l] = (uint32_t)aoff[pair_b[k]];
+                    stlen[t * 64 + l] = (uint32_t)slen(pair_b[k]);
+                }
             }
         }
+        if (b->lanes) {
+            HIPC(ctx, b->slot_toff.alloc(nt * 64 * 4));
+            HIPC(ctx, hipMemcpy(b->slot_toff.p, stoff.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+            HIPC(ctx, b->slot_tlen.alloc(nt * 64 * 4));
+            HIPC(ctx, hipMemcpy(b->slot_tlen.p, stlen.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+        }
+        mark("choose R + slot arrays");
         HIPC(ctx, b->tasks.alloc(nt * sizeof(BatchTask)));
         HIPC(ctx, hipMemcpy(b->tasks.p, tasks.data(), nt * sizeof(BatchTask), hipMemcpyHostToDevice));
         HIPC(ctx, b->slot_poff.alloc(nt * 64 * 4));
@@ -612,7 +714,12 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         if (const char* e = std::getenv("PWA_PAIRED"))
             b->paired = std::atoi(e) != 0 && !affine && !nwdist && max_strips == 2 && b->kern->fn_pair != nullptr &&
                         two_strip_tasks * 8 >= nt * 7;   // at most 1 task in 8 may leave the second wave idle
-        const void* kfn = b->single_strip ? reinterpret_cast<const void*>(b->kern->fn_single)
+        if (b->lanes) {
+            b->paired = false;
+            b->kernel_name = std::string(b->kernel_name).insert(b->kernel_name.size() - 1, ",LANES");
+        }
+        const void* kfn = b->lanes        ? reinterpret_cast<const void*>(max_strips == 1 ? b->kern->fn_lanes_single : b->kern->fn_lanes)
+                          : b->single_strip ? reinterpret_cast<const void*>(b->kern->fn_single)
                           : b->paired     ? reinterpret_cast<const void*>(b->kern->fn_pair)
                           : nwdist        ? reinterpret_cast<const void*>(b->kern->dfn)
                                  : (affine ? reinterpret_cast<const void*>(b->kern->afn) : reinterpret_cast<const void*>(b->kern->fn));
@@ -623,8 +730,22 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         b->grid = (uint32_t)std::min<uint64_t>(nt, (uint64_t)ctx->num_cu * per_cu);
         // int32 per half: one (affine: two) int4 per lane per 4-column block
         const uint64_t half = ((max_strips > 1 && !b->paired) ? ((max_m + 3) / 4 + 1) * 256 : 256) * ((affine || nwdist) ? 2 : 1);
-        HIPC(ctx, b->hand.alloc((size_t)b->grid * 2 * half * sizeof(int32_t)));
+        // Strip s reads the half written by strip s-1 and writes the other one.  With at most two strips per task
+        // the second half is only ever the parked dummy block (stride 0), so it is one block long: for C3 that
+        // turns a 10.5 GB workspace (0.24 s of hipMalloc, profiles/r01_malloc_probe.txt) into 5.2 GB (0.3 ms).
+        const uint64_t block_ints = 256 * ((affine || nwdist) ? 2 : 1);
+        const uint64_t second = (max_strips > 2 || b->paired) ? half : block_ints;
+        {   // very long texts: fewer workgroups rather than a workspace that does not fit (tasks come off a queue,
+            // any grid is correct)
+            size_t free_b = 0, total_b = 0;
+            HIPC(ctx, hipMemGetInfo(&free_b, &total_b));
+            const uint64_t per_wg = (half + second) * sizeof(int32_t);
+            const uint64_t fit = std::max<uint64_t>(1, (uint64_t)(free_b * 0.6) / per_wg);
+            b->grid = (uint32_t)std::min<uint64_t>(b->grid, fit);
+        }
+        HIPC(ctx, b->hand.alloc((size_t)b->grid * (half + second) * sizeof(int32_t)));
 
+        mark("uploads + workspace");
         BatchParams& P = b->bp;
         P.arena = b->arena.as<uint8_t>();
         P.tasks = b->tasks.as<BatchTask>();
@@ -633,7 +754,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         P.slot_out = b->slot_out.as<uint32_t>();
         P.scores = b->scores.as<int32_t>();
         P.hand = b->hand.as<int32_t>();
-        P.hand_stride = 2 * half;
+        P.hand_stride = half + second;
         P.hand_half = (uint32_t)half;
         P.queue = b->queue.as<uint32_t>();
         P.n_tasks = (uint32_t)nt;
@@ -645,6 +766,9 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         P.tab_hi = bx * 0x01010101u;                           // selectors 4..7 -> mismatch
         const uint32_t pad = (score_path == SC_PERM) ? 7u : (uint32_t)absent_byte;
         P.pad_word = pad * 0x01010101u;
+        P.tpad_word = ((score_path == SC_PERM) ? 6u : (uint32_t)std::max(text_pad_byte, 0)) * 0x01010101u;
+        P.slot_toff = b->slot_toff.as<uint32_t>();
+        P.slot_tlen = b->slot_tlen.as<uint32_t>();
     } else {
         // ---- wavefront engine, no traceback band: exact first-maximum end cells, any scoring
         const size_t nl = live.size();
@@ -754,7 +878,8 @@ int pwa_batch_run(pwa_batch* b, void* stream_v) {
                 ap.neg = b->aff_neg;
                 hipLaunchKernelGGL(b->kern->afn, dim3(b->grid), dim3(64), 0, st, ap);
             } else {
-                if (b->paired) hipLaunchKernelGGL(b->kern->fn_pair, dim3(b->grid), dim3(128), 0, st, b->bp);
+                if (b->lanes) hipLaunchKernelGGL(b->single_strip ? b->kern->fn_lanes_single : b->kern->fn_lanes, dim3(b->grid), dim3(64), 0, st, b->bp);
+                else if (b->paired) hipLaunchKernelGGL(b->kern->fn_pair, dim3(b->grid), dim3(128), 0, st, b->bp);
                 else hipLaunchKernelGGL(b->single_strip ? b->kern->fn_single : b->kern->fn, dim3(b->grid), dim3(64), 0, st, b->bp);
             }
             HIPC(ctx, hipGetLastError());

@@ -262,6 +262,42 @@ def test_two_strip_tasks_through_the_lds_paired_kernel(ctx):
         assert not bad, (scoring, bad[:5], [(len(seqs[pa[k]]), len(seqs[pb[k]]), got[k], want[k]) for k in bad[:5]])
 
 
+@pytest.mark.parametrize("alphabet,expect_lanes", [(b"ACGT", True), (b"ACGTN", True), (b"ACGTNXY", False),
+                                                   (bytes(range(65, 91)), True), (bytes(range(0, 256)), False)])
+def test_index_paired_lists_use_per_lane_texts(ctx, alphabet, expect_lanes):
+    """the reference's own shape -- pattern i against reference i (hw2.cpp:328-338), every pair its own text: local
+    scores come from the LANES kernels (each lane streams its own text; columns past a lane's text and rows past its
+    pattern are padded with two different never-matching symbols).  Ragged lengths in both directions, texts of every
+    length residue, 1..3 strips, empty and one-symbol sequences, an alphabet with no free code and one with no free
+    byte (those fall back to the other engines and must still be exact)."""
+    rng = random.Random(len(alphabet) * 7 + 1)
+    n_pairs = 700
+    pats, txts = [], []
+    for k in range(n_pairs):
+        n = rng.choice([0, 1, 2, 75, 76, 77, 150, 152, 153, 200]) if rng.random() < 0.3 else rng.randint(1, 230)
+        m = rng.choice([0, 1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257]) if rng.random() < 0.3 else rng.randint(1, 700)
+        pats.append(bytes(rng.choice(alphabet) for _ in range(n)))
+        txts.append(bytes(rng.choice(alphabet) for _ in range(m)))
+    # make a few pairs share long common substrings so that maxima sit deep inside the matrices
+    for k in range(0, n_pairs, 9):
+        if len(txts[k]) > 40:
+            cut = rng.randrange(len(txts[k]) - 30)
+            pats[k] = pats[k][:10] + txts[k][cut:cut + 30] + pats[k][10:]
+    seqs = pats + txts
+    pa = list(range(n_pairs))
+    pb = [n_pairs + k for k in range(n_pairs)]
+    for sc in [(1, -1, -1), (2, -3, -5), (5, -4, -4), (3, 0, 0)]:
+        b = ctx.batch("sw", seqs, pa, pb, *sc)
+        kern = b.info()["kernel"]
+        b.run()
+        got = b.fetch()
+        b.close()
+        assert ("LANES" in kern) == expect_lanes, (kern, sc)
+        want = [O.score("sw", seqs[a], seqs[c], *sc)[0] for a, c in zip(pa, pb)]
+        bad = [k for k in range(n_pairs) if got[k] != want[k]]
+        assert not bad, (kern, sc, bad[:5], [(len(pats[k]), len(txts[k]), got[k], want[k]) for k in bad[:5]])
+
+
 def test_batch_object_reuse(ctx, pkg):
     seqs = [O.gen(9, 0, i, 150) for i in range(130)] + [O.gen(9, 1, 0, 777)]
     pa = list(range(130))
