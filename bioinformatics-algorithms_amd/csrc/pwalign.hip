@@ -12,7 +12,9 @@
 #include <limits>
 #include <new>
 #include <numeric>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "batch_scores.hip.h"
@@ -85,6 +87,27 @@ void radix_sort_by_key(std::vector<uint64_t>& key, std::vector<uint32_t>& idx) {
         key.swap(key2);
         idx.swap(idx2);
     }
+}
+
+// Runs fn(first_seq, last_seq, thread) over the sequences, split into byte-balanced contiguous ranges, on up to
+// 16 host threads (one per >= 8 MiB): the host passes over the input (alphabet scan, symbol coding into the
+// arena) are memory-bound loops that otherwise dominate the call for inputs of hundreds of MB.
+template <class F>
+void for_seq_ranges(const uint64_t* seq_off, uint32_t n_seq, F&& fn, int* n_threads_out = nullptr) {
+    const uint64_t total = n_seq ? seq_off[n_seq] - seq_off[0] : 0;
+    int T = (int)std::min<uint64_t>({16, total / (8ull << 20) + 1, std::max(1u, std::thread::hardware_concurrency())});
+    T = std::max(1, std::min<int>(T, (int)std::max<uint32_t>(n_seq, 1)));
+    if (n_threads_out) *n_threads_out = T;
+    std::vector<uint32_t> cut((size_t)T + 1, n_seq);
+    cut[0] = 0;
+    for (int t = 1; t < T; ++t) {
+        const uint64_t want = seq_off[0] + total / (uint64_t)T * (uint64_t)t;
+        cut[(size_t)t] = (uint32_t)(std::lower_bound(seq_off, seq_off + n_seq, want) - seq_off);
+    }
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back([&, t] { fn(cut[(size_t)t], cut[(size_t)t + 1], t); });
+    fn(cut[0], cut[1], 0);
+    for (auto& x : th) x.join();
 }
 
 int fail(pwa_ctx* c, int code, const std::string& msg) {
@@ -466,9 +489,17 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         is_used[pair_a[k]] = is_used[pair_b[k]] = 1;
     }
     bool present[256] = {false};
-    for (uint32_t s = 0; s < n_seq; ++s)
-        if (is_text[s])
-            for (uint64_t o = seq_off[s]; o < seq_off[s + 1]; ++o) present[seq_bytes[o]] = true;
+    {
+        bool part[16][256] = {};
+        for_seq_ranges(seq_off, n_seq, [&](uint32_t s0, uint32_t s1, int t) {
+            bool* mine = part[t];
+            for (uint32_t s = s0; s < s1; ++s)
+                if (is_text[s])
+                    for (uint64_t o = seq_off[s]; o < seq_off[s + 1]; ++o) mine[seq_bytes[o]] = true;
+        });
+        for (int t = 0; t < 16; ++t)
+            for (int v = 0; v < 256; ++v) present[v] |= part[t][v];
+    }
     int n_alpha = 0;
     int code_of[256];
     int absent_byte = -1;
@@ -487,9 +518,15 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         bool in_pattern[256] = {false};
         std::vector<uint8_t> is_pat(n_seq, 0);
         for (uint64_t k = 0; k < n_pairs; ++k) is_pat[pair_a[k]] = 1;
-        for (uint32_t s = 0; s < n_seq; ++s)
-            if (is_pat[s])
-                for (uint64_t o = seq_off[s]; o < seq_off[s + 1]; ++o) in_pattern[seq_bytes[o]] = true;
+        bool part[16][256] = {};
+        for_seq_ranges(seq_off, n_seq, [&](uint32_t s0, uint32_t s1, int t) {
+            bool* mine = part[t];
+            for (uint32_t s = s0; s < s1; ++s)
+                if (is_pat[s])
+                    for (uint64_t o = seq_off[s]; o < seq_off[s + 1]; ++o) mine[seq_bytes[o]] = true;
+        });
+        for (int t = 0; t < 16; ++t)
+            for (int v = 0; v < 256; ++v) in_pattern[v] |= part[t][v];
         for (int v = 255; v >= 0 && text_pad_byte < 0; --v)
             if (!in_pattern[v] && v != absent_byte) text_pad_byte = v;
     }
@@ -556,20 +593,38 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
     arena_bytes += 512;   // slack: strips and text words are over-read, never over-used
     if (arena_bytes >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "sequence arena exceeds 4 GiB");
     {
-        std::vector<uint8_t> host_arena(arena_bytes, 0);
+        // not value-initialised: the threads below write every sequence byte and zero the gaps themselves
+        std::unique_ptr<uint8_t[]> host_arena_buf(new uint8_t[arena_bytes]);
+        uint8_t* const host_arena = host_arena_buf.get();
         const bool coded = b->use_strips && score_path == SC_PERM;
-        for (uint32_t s = 0; s < n_seq; ++s)
-            if (is_used[s]) {
-                uint8_t* dst = host_arena.data() + aoff[s];
-                const uint8_t* src = seq_bytes + seq_off[s];
-                const uint64_t len = slen(s);
-                if (coded)
-                    for (uint64_t o = 0; o < len; ++o) dst[o] = (uint8_t)(code_of[src[o]] >= 0 ? code_of[src[o]] : 7);
-                else
-                    std::memcpy(dst, src, len);
-            }
+        uint8_t code8[256];
+        for (int v = 0; v < 256; ++v) code8[v] = (uint8_t)(code_of[v] >= 0 ? code_of[v] : 7);
+        std::vector<uint64_t> aend(n_seq, 0);   // end of the arena region (sequence + zeroed slack) of each used sequence
+        {
+            uint64_t prev_used = n_seq;
+            for (uint32_t s = n_seq; s-- > 0;)
+                if (is_used[s]) {
+                    aend[s] = prev_used < n_seq ? aoff[prev_used] : arena_bytes;
+                    prev_used = s;
+                }
+            if (prev_used < n_seq && aoff[prev_used] > 0) std::memset(host_arena, 0, aoff[prev_used]);
+            if (prev_used == n_seq) std::memset(host_arena, 0, arena_bytes);
+        }
+        for_seq_ranges(seq_off, n_seq, [&](uint32_t s0, uint32_t s1, int) {
+            for (uint32_t s = s0; s < s1; ++s)
+                if (is_used[s]) {
+                    uint8_t* dst = host_arena + aoff[s];
+                    const uint8_t* src = seq_bytes + seq_off[s];
+                    const uint64_t len = slen(s);
+                    if (coded)
+                        for (uint64_t o = 0; o < len; ++o) dst[o] = code8[src[o]];
+                    else
+                        std::memcpy(dst, src, len);
+                    std::memset(dst + len, 0, aend[s] - aoff[s] - len);
+                }
+        });
         HIPC(ctx, b->arena.alloc(arena_bytes));
-        HIPC(ctx, hipMemcpy(b->arena.p, host_arena.data(), arena_bytes, hipMemcpyHostToDevice));
+        HIPC(ctx, hipMemcpy(b->arena.p, host_arena, arena_bytes, hipMemcpyHostToDevice));
     }
 
     mark("validate + arena upload");
