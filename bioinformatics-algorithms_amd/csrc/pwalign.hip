@@ -189,6 +189,9 @@ struct PairGeom {
 };
 PairGeom choose_geom(uint64_t max_n) {
     PairGeom g{max_n <= 32768 ? 2 : 4, 4};   // [gpu] 10k x 10k: RL=2 2.27 ms vs RL=4 2.52; 100k x 100k: RL=4 20.9 ms vs RL=2 22.0
+    // 129..256 rows: ONE 256-row stripe (W = 1, 8 workgroups per CU) instead of two 128-row stripes in a 4-stripe
+    // workgroup with two idle waves; [gpu] 4096 pairs 150 x 10k: fill 8.2 -> 7.3 ms, with the score band 12.1 -> 10.4 ms
+    if (max_n > 128 && max_n <= 256) g.rl = 4;
     if (const char* e = std::getenv("PWA_FORCE_RL")) g.rl = std::atoi(e) == 2 ? 2 : 4;   // experiments only
     if ((max_n + 64 * g.rl - 1) / (64 * g.rl) <= 1) g.w = 1;
     if (const char* e = std::getenv("PWA_FORCE_W")) g.w = std::atoi(e) == 1 ? 1 : 4;
@@ -1126,10 +1129,10 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     const uint64_t budget = std::max<uint64_t>((uint64_t)(free_b * 0.8), 64ull << 20);
     // A chunk's band is written once and read along one path per pair, so nothing is gained by a huge one, while
     // hipMalloc gets slow for very large requests ([gpu] profiles/r01_malloc_probe.txt: 0.3 ms up to 8 GiB,
-    // 0.24 s for 10.5 GB, >1 s for 16 GiB): chunks of <= 4 GiB of band (enough pairs to fill every CU; or one
+    // 0.24 s for 10.5 GB, >1 s for 16 GiB): chunks of <= 6 GiB of band (enough pairs to fill every CU; or one
     // pair, whatever it needs), all using ONE allocation sized for the largest chunk.
     // (with the int32 score band on, that one is the large allocation: 2 GiB of codes + 8 GiB of scores)
-    const uint64_t chunk_target = std::min<uint64_t>(budget, ctx->score_band ? (10ull << 30) : (4ull << 30));
+    const uint64_t chunk_target = std::min<uint64_t>(budget, ctx->score_band ? (10ull << 30) : (6ull << 30));
     struct Chunk {
         uint64_t k0, k1, band, opsb;
     };
