@@ -19,13 +19,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PWA_LIB") or os.path.join(_HERE, "libpwalign.so")   # PWA_LIB: A/B builds in experiments
 CLI_PATH = os.path.join(_HERE, "host", "hw2_amd")
+HW3_CLI_PATH = os.path.join(_HERE, "host", "hw3_amd")
 CLI4_PATH = os.path.join(_HERE, "host", "hw4_amd")
 
 MODE = {"nw": 0, "sw": 1, "global": 0, "local": 1}
 
 EXPORTS = [
     "pwa_version", "pwa_strerror", "pwa_ctx_create", "pwa_ctx_destroy", "pwa_last_error", "pwa_ctx_set_score_band", "pwa_scores",
-    "pwa_batch_create", "pwa_affine_batch_create", "pwa_scores_affine", "pwa_nwdist_batch_create", "pwa_distances", "pwa_upgma_newick", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_set_d_scores", "pwa_batch_fetch", "pwa_batch_info",
+    "pwa_batch_create", "pwa_affine_batch_create", "pwa_scores_affine", "pwa_align_affine_batch", "pwa_nwdist_batch_create", "pwa_distances", "pwa_upgma_newick", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_set_d_scores", "pwa_batch_fetch", "pwa_batch_info",
     "pwa_batch_last_ms", "pwa_batch_run_times", "pwa_batch_destroy", "pwa_align", "pwa_align_matrices", "pwa_align_last_stats", "pwa_align_batch", "pwa_overlaps",
     "pwa_cigar_bound", "pwa_mdz_bound", "pwa_format_alignment", "pwa_alignment_overlap",
     "pwa_fasta_read", "pwa_fasta_n_seq", "pwa_fasta_bytes", "pwa_fasta_offsets", "pwa_fasta_first_seq", "pwa_fasta_free",
@@ -83,6 +84,8 @@ def lib():
     L.pwa_align_last_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), u64p]
     L.pwa_align_batch.argtypes = batch_in + [i32p, vp, u64p, u64p, u64p, u64p]
     L.pwa_overlaps.argtypes = batch_in + [i32p, i32p]
+    L.pwa_align_affine_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, u64p, C.c_uint32, u32p, u32p, C.c_uint64,
+                                         i32p, vp, u64p, u64p]
     L.pwa_cigar_bound.argtypes = [C.c_uint64]
     L.pwa_cigar_bound.restype = C.c_uint64
     L.pwa_mdz_bound.argtypes = [C.c_uint64]
@@ -313,6 +316,26 @@ class Context:
             res.append(dict(score=sc[k], ops=o, end=(endc[2 * k], endc[2 * k + 1]),
                             start=(startc[2 * k], startc[2 * k + 1])))
         return res
+
+    def align_affine_batch(self, seqs, pair_a, pair_b, match, mismatch, gap_open, gap_extend):
+        """hw3.cpp:23-135 for a pair list -> [dict(score, ops)], ops in traceback order ('M' / 'D' / 'I')."""
+        blob, off, seqs = pack_sequences(seqs)
+        n = len(pair_a)
+        pa = (C.c_uint32 * max(n, 1))(*pair_a)
+        pb = (C.c_uint32 * max(n, 1))(*pair_b)
+        ooff = (C.c_uint64 * max(n, 1))()
+        tot = 0
+        for k in range(n):
+            ooff[k] = tot
+            tot += len(seqs[pair_a[k]]) + len(seqs[pair_b[k]])
+        ops = C.create_string_buffer(tot + 1)
+        sc = (C.c_int32 * max(n, 1))()
+        nops = (C.c_uint64 * max(n, 1))()
+        rc = self._L.pwa_align_affine_batch(self._h, match, mismatch, gap_open, gap_extend, blob, off, len(seqs), pa, pb, n, sc,
+                                            ops, ooff, nops)
+        self._check(rc, "pwa_align_affine_batch")
+        raw = memoryview(ops)
+        return [dict(score=sc[k], ops=bytes(raw[ooff[k]:ooff[k] + nops[k]])) for k in range(n)]
 
     def overlaps(self, mode, seqs, pair_a, pair_b, match, mismatch, gap):
         """(scores, overlaps) of full alignments without their op lists: the -g selection inputs (hw2.cpp:342-350)."""

@@ -19,6 +19,7 @@
 
 #include "batch_scores.hip.h"
 #include "batch_affine.hip.h"
+#include "batch_affine_tb.hip.h"
 #include "batch_nwdist.hip.h"
 #include "pair_fill.hip.h"
 
@@ -896,6 +897,212 @@ int pwa_distances(pwa_ctx* ctx, int match, int mismatch, int gap, const uint8_t*
     if (rc == PWA_OK) rc = pwa_batch_fetch(b, dist_out, nullptr, nullptr);
     pwa_batch_destroy(b);
     return rc;
+}
+
+// hw3.cpp:261-283: full affine-gap alignments (score + op list) of a pair list.  Pairs are grouped by string1 (for
+// the center-star step every pair has the center there): it becomes the wave's shared text and every lane runs its
+// own string2 down the rows (batch_affine_tb.hip.h).  Raw bytes, compare path, 32-row strips: the pass covers N-1
+// pairs next to the all-pairs score pass over N(N-1)/2, so it is built for exactness, not for speed.
+int pwa_align_affine_batch(pwa_ctx* ctx, int match, int mismatch, int gap_open, int gap_extend, const uint8_t* seq_bytes,
+                           const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
+                           uint64_t n_pairs, int32_t* score_out, uint8_t* ops, const uint64_t* ops_off, uint64_t* n_ops) try {
+    if (!ctx) return PWA_E_INVALID;
+    if (!seq_off || !score_out || !ops || !ops_off || !n_ops || (n_pairs && (!pair_a || !pair_b)))
+        return fail(ctx, PWA_E_INVALID, "null input");
+    if (n_seq && !seq_bytes && seq_off[n_seq] != 0) return fail(ctx, PWA_E_INVALID, "null seq_bytes");
+    if (n_pairs >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "more than 2^32-2 pairs in one batch");
+    for (uint64_t k = 0; k < n_pairs; ++k)
+        if (pair_a[k] >= n_seq || pair_b[k] >= n_seq) return fail(ctx, PWA_E_INVALID, "pair index out of range");
+    HIPC(ctx, hipSetDevice(ctx->device));
+    constexpr int R = 32, Q = R / 4;
+    auto slen = [&](uint32_t s) -> uint64_t { return seq_off[s + 1] - seq_off[s]; };
+
+    // ---- pairs with an empty side: the reference's boundary walk (hw3.cpp:42-53, 105-131) -- all 'D' or all 'I'
+    std::vector<uint32_t> live;
+    uint64_t max_m = 0;
+    for (uint64_t k = 0; k < n_pairs; ++k) {
+        const uint64_t n1 = slen(pair_a[k]), n2 = slen(pair_b[k]);
+        if (n1 > 0x3fffffffull || n2 > 0x3fffffffull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^30");
+        if (n1 == 0 || n2 == 0) {
+            score_out[k] = (n1 + n2 == 0) ? 0 : (int32_t)((uint32_t)gap_open + (uint32_t)wrap_mul((int64_t)(n1 + n2 - 1), gap_extend));
+            std::memset(ops + ops_off[k], n1 ? 'D' : 'I', n1 + n2);
+            n_ops[k] = n1 + n2;
+            continue;
+        }
+        live.push_back((uint32_t)k);
+        max_m = std::max(max_m, n1);
+    }
+    if (live.empty()) return PWA_OK;
+
+    // ---- arena: raw bytes; pad byte = one that no string1 (text) contains
+    std::vector<uint8_t> is_used(n_seq, 0);
+    bool in_text[256] = {false};
+    for (uint32_t k : live) {
+        is_used[pair_a[k]] = is_used[pair_b[k]] = 1;
+    }
+    {
+        std::vector<uint8_t> is_text(n_seq, 0);
+        for (uint32_t k : live) is_text[pair_a[k]] = 1;
+        for (uint32_t s = 0; s < n_seq; ++s)
+            if (is_text[s])
+                for (uint64_t o = seq_off[s]; o < seq_off[s + 1]; ++o) in_text[seq_bytes[o]] = true;
+    }
+    int pad_byte = -1;
+    for (int v = 255; v >= 0 && pad_byte < 0; --v)
+        if (!in_text[v]) pad_byte = v;
+    if (pad_byte < 0) return fail(ctx, PWA_E_CAPACITY, "the first sequences of the pairs use all 256 byte values: no padding symbol left");
+    std::vector<uint64_t> aoff(n_seq, 0);
+    uint64_t arena_bytes = 0;
+    for (uint32_t s = 0; s < n_seq; ++s)
+        if (is_used[s]) {
+            aoff[s] = arena_bytes;
+            arena_bytes += align_up(slen(s) + 1, 16);
+        }
+    arena_bytes += 512;
+    if (arena_bytes >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "sequence arena exceeds 4 GiB");
+    DevBuf arena;
+    {
+        std::vector<uint8_t> host_arena(arena_bytes, 0);
+        for (uint32_t s = 0; s < n_seq; ++s)
+            if (is_used[s] && slen(s)) std::memcpy(host_arena.data() + aoff[s], seq_bytes + seq_off[s], slen(s));
+        HIPC(ctx, arena.alloc(arena_bytes));
+        HIPC(ctx, hipMemcpy(arena.p, host_arena.data(), arena_bytes, hipMemcpyHostToDevice));
+    }
+
+    // ---- wave tasks: pairs grouped by string1, string2 sorted by length (descending), 64 per wave
+    std::vector<uint32_t> order(live);
+    {
+        std::vector<uint64_t> key(order.size());
+        for (size_t o = 0; o < order.size(); ++o)
+            key[o] = ((uint64_t)pair_a[order[o]] << 32) | (uint64_t)(0x7fffffffu - (uint32_t)slen(pair_b[order[o]]));
+        radix_sort_by_key(key, order);
+    }
+    struct HostTask {
+        uint32_t first, count;
+        uint64_t strips, m, tb_dwords;
+    };
+    std::vector<HostTask> ht;
+    for (size_t p = 0; p < order.size();) {
+        size_t q = p;
+        while (q < order.size() && q - p < 64 && pair_a[order[q]] == pair_a[order[p]]) ++q;
+        const uint64_t strips = (slen(pair_b[order[p]]) + R - 1) / R, m = slen(pair_a[order[p]]);
+        ht.push_back({(uint32_t)p, (uint32_t)(q - p), strips, m, strips * m * Q * 64});
+        p = q;
+    }
+
+    size_t free_b = 0, total_b = 0;
+    HIPC(ctx, hipMemGetInfo(&free_b, &total_b));
+    const uint64_t tb_budget_dw = std::max<uint64_t>(std::min<uint64_t>((uint64_t)(free_b * 0.6), 6ull << 30) / 4, 1);
+    DevBuf d_scores, d_ops, d_nops, d_queue, d_hand;
+    HIPC(ctx, d_scores.alloc(n_pairs * sizeof(int32_t)));
+    HIPC(ctx, d_nops.alloc(n_pairs * sizeof(uint32_t)));
+    HIPC(ctx, d_queue.alloc(64));
+    uint64_t ops_total = 0;
+    std::vector<uint64_t> dev_ops_off(n_pairs, 0);
+    for (uint32_t k : live) {
+        dev_ops_off[k] = ops_total;
+        ops_total += align_up(slen(pair_a[k]) + slen(pair_b[k]) + 1, 16);
+    }
+    HIPC(ctx, d_ops.alloc(ops_total));
+    const uint64_t half = ((max_m + 3) / 4 + 1) * 192 * 4;   // int32 per half: three int4 per lane per 4-column block
+    const uint32_t grid_cap = (uint32_t)std::min<uint64_t>(ht.size(), (uint64_t)ctx->num_cu * 2);
+    HIPC(ctx, d_hand.alloc((size_t)grid_cap * 2 * half * sizeof(int32_t)));
+
+    // ---- chunks of tasks whose code bands fit the budget
+    for (size_t t0 = 0; t0 < ht.size();) {
+        size_t t1 = t0;
+        uint64_t dw = 0;
+        while (t1 < ht.size() && (t1 == t0 || dw + ht[t1].tb_dwords <= tb_budget_dw)) dw += ht[t1++].tb_dwords;
+        if (dw * 4 > (uint64_t)(free_b * 0.9)) return fail(ctx, PWA_E_NOMEM, "traceback codes of one wave task exceed free HBM");
+        const size_t nt = t1 - t0;
+        std::vector<BatchTask> tasks(nt);
+        std::vector<uint32_t> spoff(nt * 64, 0), splen(nt * 64, 0), sout(nt * 64, 0xffffffffu);
+        std::vector<uint64_t> tboff(nt);
+        std::vector<AffineWalkPair> wp;
+        uint64_t at = 0;
+        for (size_t t = 0; t < nt; ++t) {
+            const HostTask& h = ht[t0 + t];
+            const uint32_t text = pair_a[order[h.first]];
+            tasks[t].text_off = (uint32_t)aoff[text];
+            tasks[t].text_len = (uint32_t)h.m;
+            tasks[t].slot0 = (uint32_t)(t * 64);
+            tasks[t].n_strips = (uint32_t)h.strips;
+            tboff[t] = at;
+            for (uint32_t l = 0; l < h.count; ++l) {
+                const uint32_t k = order[h.first + l];
+                spoff[t * 64 + l] = (uint32_t)aoff[pair_b[k]];
+                splen[t * 64 + l] = (uint32_t)slen(pair_b[k]);
+                sout[t * 64 + l] = k;
+                wp.push_back({at, dev_ops_off[k], l, (uint32_t)h.m, (uint32_t)slen(pair_b[k]), k});
+            }
+            at += h.tb_dwords;
+        }
+        DevBuf d_tb, d_tasks, d_spoff, d_splen, d_sout, d_tboff, d_wp;
+        HIPC(ctx, d_tb.alloc(dw * 4));
+        HIPC(ctx, d_tasks.alloc(nt * sizeof(BatchTask)));
+        HIPC(ctx, hipMemcpy(d_tasks.p, tasks.data(), nt * sizeof(BatchTask), hipMemcpyHostToDevice));
+        HIPC(ctx, d_spoff.alloc(nt * 64 * 4));
+        HIPC(ctx, hipMemcpy(d_spoff.p, spoff.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+        HIPC(ctx, d_splen.alloc(nt * 64 * 4));
+        HIPC(ctx, hipMemcpy(d_splen.p, splen.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+        HIPC(ctx, d_sout.alloc(nt * 64 * 4));
+        HIPC(ctx, hipMemcpy(d_sout.p, sout.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+        HIPC(ctx, d_tboff.alloc(nt * sizeof(uint64_t)));
+        HIPC(ctx, hipMemcpy(d_tboff.p, tboff.data(), nt * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIPC(ctx, d_wp.alloc(wp.size() * sizeof(AffineWalkPair)));
+        HIPC(ctx, hipMemcpy(d_wp.p, wp.data(), wp.size() * sizeof(AffineWalkPair), hipMemcpyHostToDevice));
+
+        AffineTbParams T;
+        std::memset(&T, 0, sizeof T);
+        BatchParams& P = T.a.b;
+        P.arena = arena.as<uint8_t>();
+        P.tasks = d_tasks.as<BatchTask>();
+        P.slot_poff = d_spoff.as<uint32_t>();
+        P.slot_plen = d_splen.as<uint32_t>();
+        P.slot_out = d_sout.as<uint32_t>();
+        P.scores = d_scores.as<int32_t>();
+        P.hand = d_hand.as<int32_t>();
+        P.hand_stride = 2 * half;
+        P.hand_half = (uint32_t)half;
+        P.queue = d_queue.as<uint32_t>();
+        P.n_tasks = (uint32_t)nt;
+        P.match = match;
+        P.mismatch = mismatch;
+        P.gap = gap_open;
+        P.pad_word = (uint32_t)pad_byte * 0x01010101u;
+        T.a.go = gap_open;
+        T.a.ge = gap_extend;
+        T.a.neg = std::numeric_limits<int32_t>::min() / 2;   // hw3.cpp:16
+        T.tb = d_tb.as<uint32_t>();
+        T.task_tb_off = d_tboff.as<uint64_t>();
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(nt, grid_cap);
+        HIPC(ctx, hipMemsetAsync(d_queue.p, 0, 16, ctx->stream));
+        hipLaunchKernelGGL((batch_affine_tb_kernel<R, SC_CMP>), dim3(grid), dim3(64), 0, ctx->stream, T);
+        HIPC(ctx, hipGetLastError());
+        hipLaunchKernelGGL((affine_walk_kernel<R>), dim3((uint32_t)((wp.size() + 63) / 64)), dim3(64), 0, ctx->stream,
+                           d_wp.as<AffineWalkPair>(), (uint32_t)wp.size(), d_tb.as<uint32_t>(), d_ops.as<uint8_t>(),
+                           d_nops.as<uint32_t>());
+        HIPC(ctx, hipGetLastError());
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));
+        t0 = t1;
+    }
+    std::vector<int32_t> h_scores(n_pairs);
+    std::vector<uint32_t> h_nops(n_pairs);
+    std::vector<uint8_t> h_ops(ops_total);
+    HIPC(ctx, hipMemcpy(h_scores.data(), d_scores.p, n_pairs * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPC(ctx, hipMemcpy(h_nops.data(), d_nops.p, n_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPC(ctx, hipMemcpy(h_ops.data(), d_ops.p, ops_total, hipMemcpyDeviceToHost));
+    for (uint32_t k : live) {
+        score_out[k] = h_scores[k];
+        n_ops[k] = h_nops[k];
+        if (h_nops[k] > slen(pair_a[k]) + slen(pair_b[k])) return fail(ctx, PWA_E_CAPACITY, "internal: traceback longer than n+m");
+        std::memcpy(ops + ops_off[k], h_ops.data() + dev_ops_off[k], h_nops[k]);
+    }
+    return PWA_OK;
+} catch (const std::bad_alloc&) {
+    return fail(ctx, PWA_E_NOMEM, "host allocation failed");
+} catch (...) {
+    return fail(ctx, PWA_E_HIP, "unexpected C++ exception");   // nothing may propagate across the C ABI
 }
 
 int pwa_scores_affine(pwa_ctx* ctx, int match, int mismatch, int gap_open, int gap_extend, const uint8_t* seq_bytes,

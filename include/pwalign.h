@@ -125,6 +125,21 @@ int pwa_scores_affine(pwa_ctx *ctx, int match, int mismatch, int gap_open, int g
                       uint64_t n_pairs, int32_t *score_out);
 
 /*
+ * The alignments hw3.cpp builds against the center of the star (hw3.cpp:261-283): affine_alignment(string1, string2,
+ * ..., &alignedString1, &alignedString2), i.e. hw3.cpp:23-135 with its three trace matrices, its tie-breaks (V,
+ * then F if strictly greater, then E if strictly greater; a gap is extended only if that is strictly better than
+ * opening one) and its walk.  pair (a, b): string1 = sequence a, string2 = sequence b.  Pairs that share string1
+ * (the center) are processed 64 to a wavefront.
+ *   score_out[k] : max(V, F, E)[n][m] as pwa_scores_affine
+ *   ops          : one byte per alignment column in TRACEBACK order (end -> start), pair k at ops[ops_off[k] ..):
+ *                  'M' both symbols, 'D' string1 symbol against '-', 'I' '-' against string2 symbol; the caller
+ *                  leaves room for n_k + m_k bytes per pair;   n_ops[k] : columns of pair k
+ */
+int pwa_align_affine_batch(pwa_ctx *ctx, int match, int mismatch, int gap_open, int gap_extend, const uint8_t *seq_bytes,
+                           const uint64_t *seq_off, uint32_t n_seq, const uint32_t *pair_a, const uint32_t *pair_b,
+                           uint64_t n_pairs, int32_t *score_out, uint8_t *ops, const uint64_t *ops_off, uint64_t *n_ops);
+
+/*
  * The all-pairs step of the sibling program /root/reference/hw4/hw4.cpp (138-159): per pair a
  * Needleman-Wunsch alignment with hw4's tie-break (diag >= up >= left, hw4.cpp:36-47 -- not hw2's) and
  * the number of alignment columns that hold a gap or a mismatch (146-152).  dist_out[k] is that count

@@ -69,6 +69,29 @@ def main():
     out["gen16x1000"] = {"scoring": [5, -4, -16, -4], "scores": tab, "sum": sum(tab)}
     out["gen_2000x3000"] = {"scoring": [5, -4, -16, -4],
                             "score": O.ref_affine_score(O.gen(1, 0, 0, 2000), O.gen(1, 1, 0, 3000), 5, -4, -16, -4)}
+    # alignments with traceback (hw3.cpp:23-135, strings requested): the two gapped strings of the reference
+    al = []
+    for it in range(220):
+        alpha = rng.choice([b"ACGT", b"AC", bytes(range(65, 91)), b"ACGTN"])
+        a = bytes(rng.choice(alpha) for _ in range(rng.randint(0, 70)))
+        b = bytes(rng.choice(alpha) for _ in range(rng.randint(0, 70)))
+        if rng.random() < 0.5 and a:
+            t = bytearray(a)
+            for _ in range(rng.randint(0, 5)):
+                if t:
+                    pos, op = rng.randrange(len(t)), rng.random()
+                    if op < 0.35:
+                        del t[pos:pos + rng.randint(1, 5)]
+                    elif op < 0.7:
+                        t[pos:pos] = bytes(rng.choice(alpha) for _ in range(rng.randint(1, 5)))
+                    else:
+                        t[pos] = rng.choice(alpha)
+            b = bytes(t)
+        sc = rng.choice(SCORINGS)
+        r = O.ref_affine_align(a, b, *sc)
+        assert O.affine_align(a, b, *sc)["a1"] == r["a1"] and O.affine_align(a, b, *sc)["a2"] == r["a2"], (a, b, sc)
+        al.append(dict(a=L(a), b=L(b), scoring=list(sc), score=r["score"], a1=L(r["a1"]), a2=L(r["a2"])))
+    out["alignments"] = al
     with open(os.path.join(HERE, "hw3_affine.json"), "w") as f:
         json.dump(out, f, indent=0)
     print("hw3_affine.json", os.path.getsize(os.path.join(HERE, "hw3_affine.json")))

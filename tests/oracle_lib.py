@@ -251,8 +251,52 @@ def oracle3():
         lib.orc3_affine_score.restype = C.c_int32
         lib.orc3_center.argtypes = [C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_int64)]
         lib.orc3_center.restype = C.c_size_t
+        lib.orc3_affine_align.argtypes = _SIG3
+        lib.orc3_affine_align.restype = C.POINTER(_Orc3Alignment)
+        lib.orc3_free_alignment.argtypes = [C.POINTER(_Orc3Alignment)]
+        lib.orc3_free_alignment.restype = None
+        lib.orc3_hw3_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+        lib.orc3_hw3_main.restype = C.c_int
         _lib3 = lib
     return _lib3
+
+
+class _Orc3Alignment(C.Structure):   # oracle/hw3_oracle.h: orc3_alignment
+    _fields_ = [("score", C.c_int32), ("a1", C.c_void_p), ("a2", C.c_void_p), ("ops", C.c_void_p), ("len", C.c_size_t)]
+
+
+def affine_align(s1, s2, match, mismatch, go, ge):
+    """Oracle: hw3.cpp:23-135 with strings -> dict(score, a1, a2, ops); ops in traceback order ('M'/'D'/'I')."""
+    s1, s2 = _as_bytes(s1), _as_bytes(s2)
+    lib = oracle3()
+    r = lib.orc3_affine_align(s1, len(s1), s2, len(s2), match, mismatch, go, ge)
+    if not r:
+        raise MemoryError("oracle allocation failed")
+    o = r.contents
+    out = dict(score=o.score, a1=C.string_at(o.a1, o.len), a2=C.string_at(o.a2, o.len), ops=C.string_at(o.ops, o.len))
+    lib.orc3_free_alignment(r)
+    return out
+
+
+def ref_affine_align(s1, s2, match, mismatch, go, ge):
+    """The unmodified hw3.cpp affine_alignment with the strings requested (dev container only)."""
+    ref_affine_score(b"A", b"A", 1, -1, -1, -1)   # loads _ref3
+    f = _ref3.ref3_affine_align
+    f.argtypes = _SIG3 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    f.restype = C.c_int
+    _ref3.ref3_free.argtypes = [C.c_void_p]
+    _ref3.ref3_free.restype = None
+    s1, s2 = _as_bytes(s1), _as_bytes(s2)
+    p1, p2 = C.c_void_p(), C.c_void_p()
+    score = f(s1, len(s1), s2, len(s2), match, mismatch, go, ge, C.byref(p1), C.byref(p2))
+    out = dict(score=score, a1=C.string_at(p1), a2=C.string_at(p2))
+    _ref3.ref3_free(p1)
+    _ref3.ref3_free(p2)
+    return out
+
+
+ORACLE3_CLI = os.path.join(os.path.dirname(ORACLE3_SO), "hw3_oracle_cli")
+REF3_CLI = os.path.join(os.path.dirname(REF3_SO), "hw3_ref")
 
 
 def have_ref3():

@@ -78,3 +78,80 @@ def test_affine_many_strips(ctx):
     for sc in [(5, -4, -16, -4), (1, -1, -2, -1), (100, -90, -300, -70)]:
         got = ctx.scores_affine(seqs, pa, pb, *sc)
         assert got == [O.affine_score(seqs[a], seqs[b], *sc) for a, b in zip(pa, pb)], sc
+
+
+# ------------------------------------------------------------------ alignments with traceback (hw3.cpp:23-135, 261-283)
+def test_affine_alignments_match_reference_vectors(ctx):
+    """pwa_align_affine_batch on the 220 pairs whose gapped strings came from the unmodified reference: scores and
+    every alignment column (the op list is the two strings, read backwards)."""
+    from test_oracle_hw3 import _ops_from_strings
+    recs = load_golden("hw3_affine")["alignments"]
+    by_sc = {}
+    for rec in recs:
+        by_sc.setdefault(tuple(rec["scoring"]), []).append(rec)
+    for sc, rs in by_sc.items():
+        seqs, pa, pb = [], [], []
+        for rec in rs:
+            seqs += [B(rec["a"]), B(rec["b"])]
+            pa.append(len(seqs) - 2)
+            pb.append(len(seqs) - 1)
+        got = ctx.align_affine_batch(seqs, pa, pb, *sc)
+        for g, rec in zip(got, rs):
+            assert g["score"] == rec["score"], (sc, rec)
+            assert g["ops"] == _ops_from_strings(B(rec["a1"]), B(rec["a2"])), (sc, rec)
+
+
+@pytest.mark.parametrize("alphabet", [b"ACGT", b"AC", b"ACDEFGHIKLMNPQRSTVWY"])
+def test_affine_alignments_against_a_shared_center(ctx, alphabet):
+    """the center-star shape: one string1 against many string2 (64 lanes to a wave, several waves), lengths across
+    several 32-row strips and not multiples of 4, mutated copies (long diagonal runs with gaps of every kind), empty
+    and one-symbol sequences, a second group with another string1 in the same call."""
+    rng = random.Random(len(alphabet))
+    def mutate(s, rate):
+        out = bytearray()
+        for c in s:
+            r = rng.random()
+            if r < rate / 3:
+                continue
+            if r < 2 * rate / 3:
+                out += bytes(rng.choice(alphabet) for _ in range(rng.randint(1, 6)))
+            out.append(rng.choice(alphabet) if r > 1 - rate / 3 else c)
+        return bytes(out)
+    center = bytes(rng.choice(alphabet) for _ in range(211))
+    others = [mutate(center, rng.choice([0.01, 0.05, 0.2, 0.6])) for _ in range(90)]
+    others += [b"", center[:1], center, center[:33], center[5:70], bytes(rng.choice(alphabet) for _ in range(150))]
+    center2 = bytes(rng.choice(alphabet) for _ in range(37))
+    seqs = [center, center2] + others
+    pa = [0] * len(others) + [1] * 20 + [2]
+    pb = list(range(2, 2 + len(others))) + list(range(2, 22)) + [0]
+    for sc in [(5, -4, -16, -4), (1, -1, -2, -1), (1, -1, 0, -1), (2, -1, -3, 1), (0, 0, 0, 0)]:
+        got = ctx.align_affine_batch(seqs, pa, pb, *sc)
+        for k, g in enumerate(got):
+            want = O.affine_align(seqs[pa[k]], seqs[pb[k]], *sc)
+            assert g["score"] == want["score"], (sc, k, len(seqs[pa[k]]), len(seqs[pb[k]]))
+            assert g["ops"] == want["ops"], (sc, k, len(seqs[pa[k]]), len(seqs[pb[k]]))
+
+
+def test_hw3_cli_matches_reference_cases(pkg, tmp_path):
+    """hw3_amd (both dynamic programs on the GPU, FASTA / merge / PHYLIP on the host) against the outputs of the
+    unmodified reference program: 35 cases incl. its bundled inputs, odd FASTA files, messages and exit codes."""
+    from test_oracle_hw3 import run_hw3_cases
+    run_hw3_cases(pkg.HW3_CLI_PATH, tmp_path)
+
+
+def test_hw3_cli_reproduces_reference_output_phy(pkg, tmp_path):
+    import subprocess
+    out = tmp_path / "o.phy"
+    subprocess.run([pkg.HW3_CLI_PATH, "-i", os.path.join(GOLDEN, "hw3_input.fasta"), "-o", str(out), "-s", "5:-4:-16:-4"], check=True)
+    assert out.read_bytes() == open(os.path.join(GOLDEN, "hw3_output.phy"), "rb").read()
+
+
+def test_hw3_cli_on_16_sequences_of_1000_against_oracle_cli(pkg, tmp_path):
+    """the reference's input161000.fasta (16 x 1000 bp): whole pipeline, byte for byte against the oracle's main"""
+    import subprocess
+    O.oracle3()
+    src = os.path.join(GOLDEN, "hw3_input161000.fasta")
+    a, b = tmp_path / "a.phy", tmp_path / "b.phy"
+    subprocess.run([pkg.HW3_CLI_PATH, "-i", src, "-o", str(a), "-s", "5:-4:-16:-4"], check=True)
+    subprocess.run([O.ORACLE3_CLI, "-i", src, "-o", str(b), "-s", "5:-4:-16:-4"], check=True)
+    assert a.read_bytes() == b.read_bytes()
