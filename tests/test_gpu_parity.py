@@ -298,6 +298,24 @@ def test_index_paired_lists_use_per_lane_texts(ctx, alphabet, expect_lanes):
         assert not bad, (kern, sc, bad[:5], [(len(pats[k]), len(txts[k]), got[k], want[k]) for k in bad[:5]])
 
 
+def test_index_paired_short_patterns_single_strip_lanes(ctx):
+    """per-lane texts with every pattern inside one register strip (the hand-off free LANES instantiation)"""
+    rng = random.Random(31)
+    n_pairs = 500
+    pats = [bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 40))) for _ in range(n_pairs)]
+    txts = [bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 900))) for _ in range(n_pairs)]
+    seqs = pats + txts
+    pa = list(range(n_pairs))
+    pb = [n_pairs + k for k in range(n_pairs)]
+    for sc in [(1, -1, -1), (2, -3, -5)]:
+        b = ctx.batch("sw", seqs, pa, pb, *sc)
+        assert "LANES" in b.info()["kernel"], b.info()
+        b.run()
+        got = b.fetch()
+        b.close()
+        assert got == [O.score("sw", seqs[a], seqs[c], *sc)[0] for a, c in zip(pa, pb)], sc
+
+
 def test_batch_object_reuse(ctx, pkg):
     seqs = [O.gen(9, 0, i, 150) for i in range(130)] + [O.gen(9, 1, 0, 777)]
     pa = list(range(130))
