@@ -44,6 +44,7 @@ VALU_PER_CELL = {"SC_PERM": 10.75, "SC_CMP": 12.0,   # batch_nwdist_kernel<R,SCO
                  "BM_AFFS,SC_PERM": 5.6, "BM_AFFS,SC_CMP": 7.6, "BM_AFF,SC_PERM": 7.6, "BM_AFF,SC_CMP": 9.6,
                  "BM_SWS,SC_PERM": 4.06, "BM_SWS,SC_CMP": 6.06,
                  "BM_SWS,SC_PERM,LANES": 4.11, "BM_SWS,SC_CMP,LANES": 5.6,   # per-lane texts: 1248 / 1702 VALU per 304 cells (ISA)
+                 "BM_NWG,SC_PERM,LANES": 2.58,
                  "BM_SW,SC_PERM": 5.02, "BM_SW,SC_CMP": 6.9, "BM_NW,SC_PERM": 4.5, "BM_NW,SC_CMP": 6.5,
                  "BM_NWG,SC_PERM": 2.53, "BM_NWG,SC_CMP": 4.5}
 
@@ -211,6 +212,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c3i", "c4", "c2", "c2b", "c5", "hw3", "hw4", "g", "gb"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plen", type=int, default=150, help="pattern length of the g / gb workloads (150 = the C3 shape)")
+    ap.add_argument("--nw", action="store_true", help="c3i: global (NW) instead of local scores")
     ap.add_argument("--small", action="store_true", help="reduced sizes (functional check only; line is marked invalid)")
     args = ap.parse_args()
 
@@ -246,6 +248,9 @@ def main():
     elif args.workload == "c3i":
         kw = dict(n_pairs=4096) if args.small else {}
         mode, seqs, pa, pb, scoring, desc = build_c3i(rank, **kw)
+        if args.nw:
+            mode = "nw"
+            desc["workload"] = desc["workload"].replace("SW scores-only", "NW scores-only")
         scaling = "weak"
     elif args.workload in ("hw3", "hw4"):
         kw = dict(n_seq=128) if args.small else {}
@@ -359,7 +364,7 @@ def main():
                         "as if it were written (north-star accounting), it is NOT traffic"},
     }
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and not (args.workload == "c3i" and mode == "nw"):
         with open(tpath) as f:
             tj = json.load(f)
         roofline["traffic"] = tj.get("hbm_bytes_per_launch")
@@ -367,7 +372,7 @@ def main():
 
     line = {
         "metric": "GCUPS (billion DP cells/s) SW linear-gap, 1/2/4/8xMI355X; bit-exact vs hw2.cpp"
-                  if args.workload in ("c3", "c3i") else ("GCUPS (billion DP cells/s) affine-gap all-pairs score pass; bit-exact vs hw3.cpp"
+                  if args.workload in ("c3", "c3i") and mode == "sw" else ("GCUPS (billion DP cells/s) affine-gap all-pairs score pass; bit-exact vs hw3.cpp"
                                                  if args.workload == "hw3" else
                                                  "GCUPS (billion DP cells/s) NW + traceback-derived distance, all pairs; bit-exact vs hw4.cpp"
                                                  if args.workload == "hw4" else

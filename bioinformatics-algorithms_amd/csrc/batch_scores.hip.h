@@ -55,6 +55,7 @@ struct BatchParams {
     const uint32_t* slot_out;    // per slot: index into scores
     const uint32_t* slot_toff;   // LANES kernels (every lane its own text): per slot arena offset / length of the text
     const uint32_t* slot_tlen;
+    const uint8_t* lane_text;    // LANES + BM_NWG: right-aligned, front-padded text rows (slot_toff points in here)
     int32_t* scores;
     int32_t* hand;               // strip hand-off rows, one region per workgroup
     uint64_t hand_stride;        // int32 elements per workgroup region (2 halves)
@@ -164,7 +165,12 @@ constexpr int strip_waves_per_simd(int R, int MODE) {
 // against the shared-text form, against up to 64x fewer idle lanes on index-paired lists.
 template <int R, int MODE, int SCORE, bool MULTI, bool LANES = false>
 __global__ __launch_bounds__(64, strip_waves_per_simd(R, MODE)) void batch_scores_kernel(const BatchParams P) {
-    static_assert(!LANES || MODE == BM_SWS || MODE == BM_SW, "per-lane texts: local alignment only");
+    // Global alignment, gap-shifted form, coded alphabets of <= 4 symbols: the texts of a task are RIGHT-aligned.  The
+    // host stores every lane's text as a row of M = 4*ceil(max m / 4) codes, front-padded with code 4, which the
+    // table scores like a gap (H-space g, here -g): with g <= 0 such a column reproduces column 0 exactly
+    // (H[i][j] = i*g), so a lane's real matrix simply starts p = M - m columns late, every lane ends in the last
+    // block, and H[n][m] = G'[n][M] + g(n + M).  Only row 0 differs per lane: H[0][j] = g * max(j - p, 0).
+    static_assert(!LANES || MODE == BM_SWS || MODE == BM_SW || MODE == BM_NWG, "per-lane texts: SW forms and gap-shifted NW");
     constexpr int Q = R / 4;
     const int lane = threadIdx.x;
     int32_t* const hand = P.hand + (size_t)blockIdx.x * P.hand_stride;
@@ -194,12 +200,14 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R, MODE)) void batch_score
         const uint32_t* txl = tx;
         int ml = m, last_dw = 0;
         if (LANES) {
-            txl = reinterpret_cast<const uint32_t*>(P.arena + P.slot_toff[slot]);
+            txl = reinterpret_cast<const uint32_t*>((MODE == BM_NWG ? P.lane_text : P.arena) + P.slot_toff[slot]);
             ml = (int)P.slot_tlen[slot];
             last_dw = ml > 0 ? (ml - 1) >> 2 : 0;   // loads never leave the lane's own text (+ arena slack)
         }
+        const int front_pad = LANES && MODE == BM_NWG ? 4 * nblk - ml : 0;   // p: columns ahead of the lane's own text
         // the lane's text word for block jb, symbols past the text replaced by the pad symbol
         auto lane_word = [&](int jb) -> uint32_t {
+            if (MODE == BM_NWG) return txl[min(jb, nblk - 1)];   // pre-padded row of 4 * nblk codes
             const uint32_t w = txl[min(jb, last_dw)];
             const int valid = ml - 4 * jb;
             const uint32_t keep = valid >= 4 ? 0xffffffffu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
@@ -265,7 +273,11 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R, MODE)) void batch_score
                 {
                     const int tl[4] = {tcur.x, tcur.y, tcur.z, tcur.w};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) top[k] = has_top ? tl[k] : ((MODE == BM_NW) ? mulw(4 * jb + k + 1, P.gap) : (MULTI ? 0 : zero));   // hw2.cpp:131-136
+                    for (int k = 0; k < 4; ++k) {
+                        int row0v = (MODE == BM_NW) ? mulw(4 * jb + k + 1, P.gap) : (MULTI ? 0 : zero);   // hw2.cpp:131-136
+                        if (LANES && MODE == BM_NWG) row0v = mulw(min(4 * jb + k + 1, front_pad), -P.gap);   // G' of H[0][j] = g*max(j-p,0)
+                        top[k] = has_top ? tl[k] : row0v;
+                    }
                 }
                 dp_block<R, 4, MODE, SCORE>(H, Hs, pk, cs, top, topprev, bot, best, P);
                 if (MULTI) hout4[(size_t)jb * out_stride] = make_int4(bot[0], bot[1], bot[2], bot[3]);

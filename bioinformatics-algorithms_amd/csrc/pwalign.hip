@@ -161,7 +161,7 @@ const BatchKernelEntry kBatchKernels[] = {
     BK(64, BM_SW, SC_CMP),    BK(128, BM_SW, SC_CMP),   BK(152, BM_SW, SC_CMP),
     BK(64, BM_NW, SC_PERM),   BK(128, BM_NW, SC_PERM),  BK(152, BM_NW, SC_PERM),
     BK(64, BM_NW, SC_CMP),    BK(128, BM_NW, SC_CMP),   BK(152, BM_NW, SC_CMP),
-    BK(64, BM_NWG, SC_PERM),  BK(128, BM_NWG, SC_PERM), BK(152, BM_NWG, SC_PERM),
+    BKL(64, BM_NWG, SC_PERM), BKL(128, BM_NWG, SC_PERM), BKL(152, BM_NWG, SC_PERM),
     BK(64, BM_NWG, SC_CMP),   BK(128, BM_NWG, SC_CMP),  BK(152, BM_NWG, SC_CMP),
 #define AK(R, M, S, SH) {R, M, S, nullptr, "batch_affine_kernel<R=" #R "," #M "," #S ">", batch_affine_kernel<R, S, SH>}
     AK(32, BM_AFFS, SC_PERM, true),  AK(52, BM_AFFS, SC_PERM, true),  AK(32, BM_AFFS, SC_CMP, true),  AK(52, BM_AFFS, SC_CMP, true),
@@ -322,7 +322,7 @@ struct pwa_batch {
     bool affine = false, nwdist = false, single_strip = false, paired = false, lanes = false;
     int32_t aff_go = 0, aff_ge = 0, aff_neg = 0;
     uint32_t grid = 0;
-    DevBuf arena, tasks, slot_poff, slot_plen, slot_out, slot_toff, slot_tlen, hand, queue, scores;
+    DevBuf arena, tasks, slot_poff, slot_plen, slot_out, slot_toff, slot_tlen, lane_text, hand, queue, scores;
     // engine 2: wavefront kernels without traceback band (exact end cells, any scoring)
     PairLaunch pl;
     DevBuf pair_res;
@@ -517,6 +517,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
 
     // LANES kernels also pad TEXTS (columns past a lane's own text): that symbol must match no pattern symbol and
     // must differ from the pattern pad, or padded rows would "match" padded columns.
+    bool pattern_has[256] = {false};
     int text_pad_byte = -1;   // raw-byte (SC_CMP) form; the coded (SC_PERM) form uses code 6 when the alphabet leaves it free
     {
         bool in_pattern[256] = {false};
@@ -533,6 +534,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             for (int v = 0; v < 256; ++v) in_pattern[v] |= part[t][v];
         for (int v = 255; v >= 0 && text_pad_byte < 0; --v)
             if (!in_pattern[v] && v != absent_byte) text_pad_byte = v;
+        for (int v = 0; v < 256; ++v) pattern_has[v] = in_pattern[v];
     }
 
     // ---- engine choice.  The strip engine pads short patterns with rows that match nothing; for SW
@@ -660,8 +662,17 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         bool kernels_have_lanes = false;
         for (const auto& e : kBatchKernels) kernels_have_lanes |= (e.fn_lanes != nullptr && e.score == score_path);
         const bool text_pad_ok = score_path == SC_PERM ? n_alpha <= 6 : text_pad_byte >= 0;
-        b->lanes = kmode == BM_SW && !affine && !nwdist && kernels_have_lanes && text_pad_ok &&
-                   ht.size() * 64 > order.size() * 3 / 2 + 64 && !std::getenv("PWA_PAIRED");   // (the opt-in experiment wins)
+        const bool underfilled = ht.size() * 64 > order.size() * 3 / 2 + 64;
+        b->lanes = kmode == BM_SW && !affine && !nwdist && kernels_have_lanes && text_pad_ok && underfilled &&
+                   !std::getenv("PWA_PAIRED");   // (the opt-in experiment wins)
+        // global alignment: right-aligned texts, front-padded with a code the table scores like a gap (batch_scores.hip.h).
+        // Needs the gap-shifted form, a coded alphabet with codes 4..7 free, every pattern symbol inside it (a
+        // pattern-only symbol shares code 7 with the pad rows), g <= 0 and -g in a table byte.
+        bool patterns_inside = true;
+        for (int v = 0; v < 256; ++v) patterns_inside = patterns_inside && (!pattern_has[v] || present[v]);
+        const bool lanes_nw = kmode == BM_NWG && !affine && !nwdist && score_path == SC_PERM && n_alpha <= 4 && patterns_inside &&
+                              gap <= 0 && fits8(-gap) && underfilled;
+        b->lanes = b->lanes || lanes_nw;
         if (const char* e = std::getenv("PWA_FORCE_LANES")) b->lanes = b->lanes && std::atoi(e) != 0;   // experiments only
         if (b->lanes) {
             order = live;
@@ -748,6 +759,32 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
                 }
             }
         }
+        if (b->lanes && kmode == BM_NWG) {
+            // right-aligned, front-padded (code 4) text rows: task t, lane l at t_base + l * M_t, M_t = 4 * ceil(max m / 4)
+            uint64_t total = 0;
+            std::vector<uint64_t> tbase(nt);
+            for (size_t t = 0; t < nt; ++t) {
+                tbase[t] = total;
+                total += 64ull * ((ht[t].m + 3) / 4 * 4);
+            }
+            if (total + 64 >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "per-lane text rows exceed 4 GiB");
+            std::unique_ptr<uint8_t[]> rows(new uint8_t[total + 64]);
+            std::memset(rows.get(), 4, total + 64);
+            for (size_t t = 0; t < nt; ++t) {
+                const uint64_t M = (ht[t].m + 3) / 4 * 4;
+                tasks[t].text_len = (uint32_t)M;
+                for (uint32_t l = 0; l < ht[t].count; ++l) {
+                    const uint32_t k = order[ht[t].first + l];
+                    const uint8_t* src = seq_bytes + seq_off[pair_b[k]];
+                    const uint64_t len = slen(pair_b[k]);
+                    uint8_t* dst = rows.get() + tbase[t] + (uint64_t)l * M + (M - len);
+                    for (uint64_t o = 0; o < len; ++o) dst[o] = (uint8_t)code_of[src[o]];
+                    stoff[t * 64 + l] = (uint32_t)(tbase[t] + (uint64_t)l * M);
+                }
+            }
+            HIPC(ctx, b->lane_text.alloc(total + 64));
+            HIPC(ctx, hipMemcpy(b->lane_text.p, rows.get(), total + 64, hipMemcpyHostToDevice));
+        }
         if (b->lanes) {
             HIPC(ctx, b->slot_toff.alloc(nt * 64 * 4));
             HIPC(ctx, hipMemcpy(b->slot_toff.p, stoff.data(), nt * 64 * 4, hipMemcpyHostToDevice));
@@ -826,6 +863,8 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         const uint32_t pad = (score_path == SC_PERM) ? 7u : (uint32_t)absent_byte;
         P.pad_word = pad * 0x01010101u;
         P.tpad_word = ((score_path == SC_PERM) ? 6u : (uint32_t)std::max(text_pad_byte, 0)) * 0x01010101u;
+        P.lane_text = b->lane_text.as<uint8_t>();
+        if (b->lanes && kmode == BM_NWG) P.tab_hi = (uint32_t)(uint8_t)(int8_t)(-gap) * 0x01010101u;   // selectors 4..7: front pad = a gap column
         P.slot_toff = b->slot_toff.as<uint32_t>();
         P.slot_tlen = b->slot_tlen.as<uint32_t>();
     } else {

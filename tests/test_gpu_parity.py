@@ -298,6 +298,40 @@ def test_index_paired_lists_use_per_lane_texts(ctx, alphabet, expect_lanes):
         assert not bad, (kern, sc, bad[:5], [(len(pats[k]), len(txts[k]), got[k], want[k]) for k in bad[:5]])
 
 
+@pytest.mark.parametrize("alphabet,pattern_extra,expect_lanes", [(b"ACGT", b"", True), (b"AC", b"", True), (b"ACGTN", b"", False),
+                                                                 (b"ACGT", b"N", False)])
+def test_index_paired_global_scores_use_right_aligned_lanes(ctx, alphabet, pattern_extra, expect_lanes):
+    """global alignment scores of index-paired lists: LANES kernels with right-aligned texts whose front padding the
+    table scores like a gap column (alphabets of <= 4 symbols that contain every pattern symbol); other inputs keep
+    the text-grouped form.  Ragged lengths both ways, every length residue mod 4, 1..3 strips, one-symbol and empty
+    sequences; scorings with gap 0 and with tables that no longer fit a byte (those leave the gap-shifted form)."""
+    rng = random.Random(len(alphabet) * 11 + len(pattern_extra))
+    n_pairs = 600
+    pats, txts = [], []
+    for k in range(n_pairs):
+        n = rng.choice([0, 1, 2, 63, 64, 65, 128, 152, 153, 300]) if rng.random() < 0.3 else rng.randint(1, 330)
+        m = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 255, 256, 257]) if rng.random() < 0.3 else rng.randint(1, 600)
+        pats.append(bytes(rng.choice(alphabet + pattern_extra) for _ in range(n)))
+        txts.append(bytes(rng.choice(alphabet) for _ in range(m)))
+    for k in range(0, n_pairs, 7):   # related pairs: long diagonals
+        if len(txts[k]) > 30:
+            pats[k] = txts[k][3:] if k % 2 else txts[k][:len(txts[k]) // 2] + pats[k][:20]
+    seqs = pats + txts
+    pa = list(range(n_pairs))
+    pb = [n_pairs + k for k in range(n_pairs)]
+    for sc, shifted in [((1, -1, -1), True), ((2, -3, -5), True), ((5, -4, -4), True), ((1, -1, 0), True), ((3, 0, -2), True),
+                        ((100, -90, -70), False)]:
+        b = ctx.batch("nw", seqs, pa, pb, *sc)
+        kern = b.info()["kernel"]
+        b.run()
+        got = b.fetch()
+        b.close()
+        assert ("LANES" in kern) == (expect_lanes and shifted), (kern, sc)
+        want = [O.score("nw", seqs[a], seqs[c], *sc)[0] for a, c in zip(pa, pb)]
+        bad = [k for k in range(n_pairs) if got[k] != want[k]]
+        assert not bad, (kern, sc, bad[:5], [(len(pats[k]), len(txts[k]), got[k], want[k]) for k in bad[:5]])
+
+
 def test_index_paired_short_patterns_single_strip_lanes(ctx):
     """per-lane texts with every pattern inside one register strip (the hand-off free LANES instantiation)"""
     rng = random.Random(31)
