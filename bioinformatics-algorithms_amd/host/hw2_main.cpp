@@ -16,7 +16,11 @@
 //        band + device walk that returns the overlap, no op lists) + ONE full alignment for the winner;
 //   neither flag: the reference computes and then writes an EMPTY file (379-393) => no GPU work.
 //
-// One extra, non-colliding option: --device N (HIP device ordinal, default 0).
+// Extra, non-colliding options: --device N (HIP device ordinal, default 0) and --devices a,b,c: the pair list is cut
+// into contiguous equal blocks, one per listed GPU, each driven by its own host thread and context (pairs are
+// independent, hw2.cpp:328-338; the per-pair results land in host memory, so no collective is needed in one process);
+// first-best selection over the merged vector keeps the reference's loop order.
+#include <algorithm>
 #include <cctype>
 #include <cstdint>
 #include <cstdio>
@@ -25,6 +29,7 @@
 #include <fstream>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pwalign.h"
@@ -68,6 +73,7 @@ int main(int argc, char* argv[]) {
     bool global = false, local = false;
     std::string pattern_file, reference_file, output_file;
     int match = 0, mismatch = 0, gap = 0, device = 0;
+    std::vector<int> devices;
     for (int i = 1; i < argc; ++i) {   // hw2.cpp:290-307; unknown tokens are ignored
         const std::string a = argv[i];
         if (a == "-g") global = true;
@@ -80,7 +86,17 @@ int main(int argc, char* argv[]) {
             mismatch = std::atoi(argv[++i]);
             gap = std::atoi(argv[++i]);
         } else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
+        else if (a == "--devices" && i + 1 < argc) {
+            const std::string list = argv[++i];
+            for (size_t b = 0; b <= list.size();) {
+                const size_t e = std::min(list.find(',', b), list.size());
+                if (e > b) devices.push_back(std::atoi(list.substr(b, e - b).c_str()));
+                b = e + 1;
+            }
+        }
     }
+    if (devices.empty()) devices.push_back(device);
+    device = devices[0];
 
     // readFasta (hw2.cpp:25-57) for both files: one blob + offsets, the layout the engine takes (pwa_fasta_read).
     // The reference reads the pattern file first and exits at the first file it cannot open (28-31, 317-318).
@@ -125,6 +141,42 @@ int main(int argc, char* argv[]) {
         int rc = pwa_ctx_create(device, &ctx);
         if (rc != PWA_OK) return engine_error(nullptr, "opening the MI355X device (no CPU fallback exists)", rc);
 
+        // the per-pair pass over contiguous blocks of the pair list, one block per listed device (block 0 on `ctx`)
+        pwa_ctx* rc_ctx = nullptr;   // context whose error text belongs to a failure (kept alive until reported)
+        std::vector<pwa_ctx*> extra;
+        struct ExtraGuard {
+            std::vector<pwa_ctx*>& v;
+            ~ExtraGuard() {
+                for (pwa_ctx* c : v) pwa_ctx_destroy(c);
+            }
+        } extra_guard{extra};
+        auto sharded = [&](auto&& pass) -> int {
+            const size_t D = std::min(devices.size(), np);
+            if (D <= 1) return pass(ctx, (size_t)0, np);
+            for (size_t d = 1; d < D; ++d) {
+                pwa_ctx* c = nullptr;
+                const int r = pwa_ctx_create(devices[d], &c);
+                if (r != PWA_OK) return r;
+                extra.push_back(c);
+            }
+            std::vector<int> rcs(D, PWA_OK);
+            std::vector<std::thread> th;
+            const size_t per = (np + D - 1) / D;
+            auto run = [&](size_t d) {
+                const size_t k0 = std::min(np, d * per), k1 = std::min(np, k0 + per);
+                rcs[d] = k1 > k0 ? pass(d == 0 ? ctx : extra[d - 1], k0, k1) : PWA_OK;
+            };
+            for (size_t d = 1; d < D; ++d) th.emplace_back(run, d);
+            run(0);
+            for (auto& t : th) t.join();
+            for (size_t d = 0; d < D; ++d)
+                if (rcs[d] != PWA_OK) {
+                    rc_ctx = d == 0 ? ctx : extra[d - 1];
+                    return rcs[d];
+                }
+            return PWA_OK;
+        };
+
         // one full alignment through the engine, rebuilt into the report's strings (both modes print only the winner)
         auto align_winner = [&](int mode, int32_t expect_score, int32_t expect_overlap) -> int {
             const std::string p = seq((size_t)best_index), t = seq(np + (size_t)best_index);
@@ -146,10 +198,12 @@ int main(int argc, char* argv[]) {
             // hw2.cpp:342-350 keeps only each pair's overlap length: the device walk returns it, no op list leaves
             // the GPU (pwa_overlaps); the winner is then aligned once more for its strings
             std::vector<int32_t> scores(np), overlaps(np);
-            rc = pwa_overlaps(ctx, PWA_MODE_NW, match, mismatch, gap, bytes, off, (uint32_t)(2 * np), pa.data(), pb.data(),
-                              np, scores.data(), overlaps.data());
+            rc = sharded([&](pwa_ctx* c, size_t k0, size_t k1) {
+                return pwa_overlaps(c, PWA_MODE_NW, match, mismatch, gap, bytes, off, (uint32_t)(2 * np), pa.data() + k0,
+                                    pb.data() + k0, k1 - k0, scores.data() + k0, overlaps.data() + k0);
+            });
             if (rc != PWA_OK) {
-                const int e = engine_error(ctx, "pwa_overlaps", rc);
+                const int e = engine_error(rc_ctx ? rc_ctx : ctx, "pwa_overlaps", rc);
                 pwa_ctx_destroy(ctx);
                 return e;
             }
@@ -165,10 +219,12 @@ int main(int argc, char* argv[]) {
             }
         } else {
             std::vector<int32_t> scores(np);
-            rc = pwa_scores(ctx, PWA_MODE_SW, match, mismatch, gap, bytes, off, (uint32_t)(2 * np), pa.data(), pb.data(),
-                            np, scores.data(), nullptr, nullptr);
+            rc = sharded([&](pwa_ctx* c, size_t k0, size_t k1) {
+                return pwa_scores(c, PWA_MODE_SW, match, mismatch, gap, bytes, off, (uint32_t)(2 * np), pa.data() + k0,
+                                  pb.data() + k0, k1 - k0, scores.data() + k0, nullptr, nullptr);
+            });
             if (rc != PWA_OK) {
-                const int e = engine_error(ctx, "pwa_scores", rc);
+                const int e = engine_error(rc_ctx ? rc_ctx : ctx, "pwa_scores", rc);
                 pwa_ctx_destroy(ctx);
                 return e;
             }

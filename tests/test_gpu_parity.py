@@ -447,6 +447,43 @@ def test_cli_many_pairs_against_oracle_cli(pkg, tmp_path):
             assert a.read_bytes() == b.read_bytes()
 
 
+def test_cli_sharded_over_devices_matches_oracle_cli(pkg, tmp_path):
+    """--devices a,b,c: contiguous blocks of the pair list, one host thread + context per listed GPU (here the same GPU
+    several times: the threading, the block arithmetic incl. more devices than pairs, and the first-best selection
+    over the merged vectors); ties between blocks must still go to the first pair."""
+    rng = random.Random(13)
+    with open(tmp_path / "p.fa", "w") as fp, open(tmp_path / "t.fa", "w") as ft:
+        for i in range(203):
+            p = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 160)))
+            t = "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 300)))
+            if i in (40, 150):   # the same best pair twice, in different blocks: the first one must win
+                p, t = "ACGTACGTTTGACCAGTACCAGTT" * 3, "GG" + "ACGTACGTTTGACCAGTACCAGTT" * 3 + "CA"
+            fp.write(">p%d\n%s\n" % (i, p))
+            ft.write(">t%d\n%s\n" % (i, t))
+    with open(tmp_path / "p2.fa", "w") as fp, open(tmp_path / "t2.fa", "w") as ft:
+        fp.write(">a\nACGTAC\n>b\nTTGACA\n")
+        ft.write(">a\nACGAC\n>b\nTTGCA\n")
+    O.oracle()
+    for flag in ("-g", "-l"):
+        b = tmp_path / "b.txt"
+        args = [flag, "-p", "p.fa", "-t", "t.fa", "-s", 1, -1, -1]
+        assert O.run_cli(O.ORACLE_CLI, args + ["-o", b], cwd=tmp_path)[0] == 0
+        for devs in ("0,0", "0,0,0,0,0", "0"):
+            a = tmp_path / "a.txt"
+            rc, err = O.run_cli(pkg.CLI_PATH, args + ["-o", a, "--devices", devs], cwd=tmp_path)
+            assert rc == 0, err
+            assert a.read_bytes() == b.read_bytes(), (flag, devs)
+        args2 = [flag, "-p", "p2.fa", "-t", "t2.fa", "-s", 1, -1, -1]
+        assert O.run_cli(O.ORACLE_CLI, args2 + ["-o", b], cwd=tmp_path)[0] == 0
+        a = tmp_path / "a.txt"
+        rc, err = O.run_cli(pkg.CLI_PATH, args2 + ["-o", a, "--devices", "0,0,0,0"], cwd=tmp_path)   # more devices than pairs
+        assert rc == 0, err
+        assert a.read_bytes() == b.read_bytes()
+    rc, err = O.run_cli(pkg.CLI_PATH, ["-l", "-p", "p.fa", "-t", "t.fa", "-s", 1, -1, -1, "-o", tmp_path / "a.txt", "--devices", "0,99"],
+                        cwd=tmp_path)
+    assert rc == 2 and b"no usable gfx950 device" in err or b"failed" in err
+
+
 def test_device_score_vector_in_caller_memory(ctx):
     """pwa_batch_set_d_scores: kernels write into a torch tensor (what bench.py hands to the RCCL all-gather);
     both engines, including pairs with an empty side."""
