@@ -213,4 +213,167 @@ __global__ __launch_bounds__(64, nwdist_waves_per_simd(R)) void batch_nwdist_ker
     }
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------
+// Packed form: (H, dist) of a cell as ONE int32 key, so that one v_max3 both picks hw4's predecessor and carries
+// its distance along:
+//     K = H * 2^14  +  prio * 2^12  +  dist,      prio: diag 2, up 1, left 0  (hw4.cpp:36-47: diag >= up >= left)
+// Keys compare by H first, then by the direction's priority; dist sits below and can never decide (two candidates
+// of one cell always differ in prio).  Stored per row: L = key without prio + (gap * 2^14 + 1), i.e. the candidate
+// the cell to the RIGHT sees; the cell BELOW adds 2^12 to it (prio 1); the DIAGONAL consumer adds
+// ((s - gap) * 2^14 + 2 * 2^12 + e - 1), one of two constants picked by the symbol compare.
+// Per cell: cmp, cndmask, add (diag), add (up), max3, and (strip prio), add = 7 VALU against 10.75, one hand-off
+// value per column instead of two.  Valid while dist < 4094 and |H| stays inside 17 bits (host check); the plain
+// form above takes everything else.
+constexpr int kDistBits = 12, kPrioShift = 12, kHShift = 14;
+
+template <int R, int C>
+__device__ __forceinline__ void nwdist_packed_block(int (&L)[R], const uint32_t (&pk)[R / 4], const uint32_t (&cs)[C],
+                                                    const int (&ltop)[C], int& lprev, int (&lbot)[C], int cd_match, int cd_mis,
+                                                    int cl) {
+    constexpr int Q = R / 4;
+    int dk[C], uk[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        dk[k] = (k == 0) ? lprev : ltop[k - 1];   // L of the row above, previous column
+        uk[k] = ltop[k];                          // L of the row above, this column
+    }
+    lprev = ltop[C - 1];
+#pragma unroll
+    for (int step = 0; step < Q + C - 1; ++step) {
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int q = step - k;
+            if (q >= 0 && q < Q) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int r = 4 * q + b;
+                    const bool eq = ((pk[q] >> (8 * b)) & 0xffu) == cs[k];
+                    const int kd = addw(dk[k], eq ? cd_match : cd_mis);   // diag: H + s, dist + (mismatch), prio 2
+                    const int ku = addw(uk[k], 1 << kPrioShift);          // up:   H + gap, dist + 1,        prio 1
+                    const int kl = L[r];                                  // left: H + gap, dist + 1,        prio 0
+                    dk[k] = kl;
+                    const int best = max(kd, max(ku, kl));
+                    const int l = addw(best & ~(3 << kPrioShift), cl);
+                    L[r] = l;
+                    uk[k] = l;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < C; ++k) lbot[k] = uk[k];
+}
+
+template <int R>
+__global__ __launch_bounds__(64, 2) void batch_nwdist_packed_kernel(const NwDistParams P) {
+    constexpr int Q = R / 4;
+    const BatchParams& B = P.b;
+    const int lane = threadIdx.x;
+    int32_t* const hand = B.hand + (size_t)blockIdx.x * B.hand_stride;
+    // here B.match / B.mismatch / B.gap are hw4's own three scores (not the (s - gap) tables of the plain form)
+    const int gap = B.gap;
+    const int cl = addw(mulw(gap, 1 << kHShift), 1);
+    const int cd_match = addw(mulw(B.match - gap, 1 << kHShift), (2 << kPrioShift) - 1);
+    const int cd_mis = addw(mulw(B.mismatch - gap, 1 << kHShift), (2 << kPrioShift));
+    // L of a boundary cell with H = x * gap, dist = x (hw4.cpp:21-28)
+    auto boundary = [&](int x) -> int { return addw(addw(mulw(mulw(x, gap), 1 << kHShift), x), cl); };
+
+    for (;;) {
+        uint32_t tid = 0;
+        {
+            int elect = lane;   // opaque electing lane: see batch_scores.hip.h
+            asm volatile("" : "+v"(elect));
+            if (elect == 0) tid = atomicAdd(B.queue, 1u);
+        }
+        tid = __builtin_amdgcn_readfirstlane(tid);
+        if (tid >= B.n_tasks) break;
+
+        const BatchTask task = B.tasks[tid];
+        const int m = (int)task.text_len;
+        const uint32_t* tx = reinterpret_cast<const uint32_t*>(B.arena + task.text_off);
+        const uint32_t slot = task.slot0 + lane;
+        const uint32_t poff = B.slot_poff[slot];
+        const int n = (int)B.slot_plen[slot];
+        const uint32_t outi = B.slot_out[slot];
+        const int nblk = m >> 2, rem = m & 3;
+        int res = 0;
+
+        for (int s = 0; s < (int)task.n_strips; ++s) {
+            const int row0 = s * R;
+            uint32_t pk[Q];
+            {
+                const uint32_t* pp = reinterpret_cast<const uint32_t*>(B.arena + poff + row0);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const int valid = n - (row0 + 4 * q);
+                    const uint32_t w = pp[q];
+                    const uint32_t keep = valid >= 4 ? 0xffffffffu : (valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u));
+                    pk[q] = (w & keep) | (B.pad_word & ~keep);
+                }
+            }
+            int L[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) L[r] = boundary(row0 + r + 1);   // column 0
+            int lprev = boundary(row0);                                  // row above the strip, column 0
+
+            const bool has_top = s > 0;
+            const bool has_bot = s + 1 < (int)task.n_strips;
+            const int32_t* hin = hand + (size_t)((s + 1) & 1) * B.hand_half;
+            int32_t* hout = hand + (size_t)(s & 1) * B.hand_half;
+            const size_t in_stride = has_top ? 64 : 0, out_stride = has_bot ? 64 : 0;   // one int4 per lane per block
+            const int4* hin4 = reinterpret_cast<const int4*>(hin) + lane;
+            int4* hout4 = reinterpret_cast<int4*>(hout) + lane;
+            int4 lnext = hin4[0];
+            uint32_t cwn = tx[0];
+            for (int jb = 0; jb < nblk; ++jb) {
+                const uint32_t cw = cwn;
+                const int4 lcur = lnext;
+                cwn = tx[jb + 1];
+                lnext = hin4[(size_t)(jb + 1) * in_stride];
+                int ltop[4], lbot[4];
+                uint32_t cs[4];
+                const int ll[4] = {lcur.x, lcur.y, lcur.z, lcur.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    cs[k] = (cw >> (8 * k)) & 0xffu;
+                    ltop[k] = has_top ? ll[k] : boundary(4 * jb + k + 1);   // row 0
+                }
+                nwdist_packed_block<R, 4>(L, pk, cs, ltop, lprev, lbot, cd_match, cd_mis, cl);
+                hout4[(size_t)jb * out_stride] = make_int4(lbot[0], lbot[1], lbot[2], lbot[3]);
+            }
+            if (rem > 0) {
+                uint32_t cw = cwn;
+                int l0 = lnext.x, l1 = lnext.y, l2 = lnext.z;
+#pragma unroll 1
+                for (int k = 0; k < rem; ++k) {
+                    const uint32_t cs1[1] = {cw & 0xffu};
+                    cw >>= 8;
+                    const int ltop1[1] = {has_top ? l0 : boundary(4 * nblk + k + 1)};
+                    l0 = l1;
+                    l1 = l2;
+                    int lbot1[1];
+                    nwdist_packed_block<R, 1>(L, pk, cs1, ltop1, lprev, lbot1, cd_match, cd_mis, cl);
+                    hout[((size_t)nblk * out_stride + lane) * 4 + k] = lbot1[0];
+                }
+            }
+            {   // the key of (n, m) sits in this strip for the lanes whose pattern ends here
+                const int rl = n - 1 - row0;
+                if (rl >= 0 && rl < R) {
+                    int v = 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) v = (rl == r) ? L[r] : v;
+                    res = v;
+                }
+            }
+        }
+        if (outi != 0xffffffffu) {
+            const int key = addw(res, -cl);                                        // H * 2^14 + dist
+            B.scores[outi] = key & ((1 << kDistBits) - 1);                        // hw4.cpp:146-152
+            if (P.scores2) P.scores2[outi] = key >> kHShift;                      // dp[n][m]
+        }
+    }
+}
+
 }  // namespace pwa

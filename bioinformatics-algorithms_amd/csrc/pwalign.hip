@@ -133,7 +133,7 @@ inline int32_t wrap_mul(int64_t a, int32_t b) { return (int32_t)((uint32_t)a * (
 typedef void (*batch_kernel_t)(const BatchParams);
 typedef void (*affine_kernel_t)(const AffineParams);
 typedef void (*nwdist_kernel_t)(const NwDistParams);
-enum { BM_AFF = 3, BM_AFFS = 4, BM_DIST = 5 };   // affine (hw3) plain / shifted, hw4 NW + distance; 0..2: batch_scores.hip.h
+enum { BM_AFF = 3, BM_AFFS = 4, BM_DIST = 5, BM_DISTP = 7 };   // (6 = BM_SWS, batch_scores.hip.h); 7: packed-key hw4 form   // affine (hw3) plain / shifted, hw4 NW + distance; 0..2: batch_scores.hip.h
 struct BatchKernelEntry {
     int R, mode, score;
     batch_kernel_t fn;       // multi-strip form (strip hand-off rows through HBM)
@@ -169,6 +169,9 @@ const BatchKernelEntry kBatchKernels[] = {
 #undef AK
 #define DK(R, S) {R, BM_DIST, S, nullptr, "batch_nwdist_kernel<R=" #R "," #S ">", nullptr, batch_nwdist_kernel<R, S>}
     DK(32, SC_PERM), DK(64, SC_PERM), DK(32, SC_CMP), DK(64, SC_CMP),
+#define DKP(R, S) {R, BM_DISTP, S, nullptr, "batch_nwdist_kernel<R=" #R ",PACKED>", nullptr, batch_nwdist_packed_kernel<R>}
+    DKP(64, SC_PERM), DKP(128, SC_PERM), DKP(64, SC_CMP), DKP(128, SC_CMP),   // one compare-based kernel for both codings
+#undef DKP
 #undef DK
 };
 #undef BK
@@ -556,6 +559,14 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         if (n_alpha <= 7 && fits8(tab_match) && fits8(tab_mismatch)) score_path = SC_PERM;
         if (score_path == SC_CMP && absent_byte < 0)
             return fail(ctx, PWA_E_INVALID, "distance pass: the texts use all 256 byte values, no padding symbol left");
+        // packed (H, dist) keys: dist in 12 bits, H in the 18 above (batch_nwdist.hip.h)
+        const int64_t amax = std::max<int64_t>({std::llabs((long long)match), std::llabs((long long)mismatch),
+                                                std::llabs((long long)gap)});
+        if (max_n + max_m <= 4000 && (int64_t)(max_n + max_m + 2) * amax < 65536 && !std::getenv("PWA_NO_PACKED_DIST")) {
+            kmode = BM_DISTP;
+            tab_match = match;       // the packed kernel takes hw4's own three scores
+            tab_mismatch = mismatch;
+        }
     } else if (affine) {
         // Ge(i+j)-shifted form when every value stays far inside int32 (the sentinels are -2^29 there)
         const int64_t amax = std::max<int64_t>({std::llabs((long long)match), std::llabs((long long)mismatch),
@@ -825,11 +836,12 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         per_cu = std::max(1, std::min(per_cu, 32));
         b->grid = (uint32_t)std::min<uint64_t>(nt, (uint64_t)ctx->num_cu * per_cu);
         // int32 per half: one (affine: two) int4 per lane per 4-column block
-        const uint64_t half = ((max_strips > 1 && !b->paired) ? ((max_m + 3) / 4 + 1) * 256 : 256) * ((affine || nwdist) ? 2 : 1);
+        const int hand_vals = (affine || (nwdist && kmode != BM_DISTP)) ? 2 : 1;   // int4 per lane per 4-column block
+        const uint64_t half = ((max_strips > 1 && !b->paired) ? ((max_m + 3) / 4 + 1) * 256 : 256) * hand_vals;
         // Strip s reads the half written by strip s-1 and writes the other one.  With at most two strips per task
         // the second half is only ever the parked dummy block (stride 0), so it is one block long: for C3 that
         // turns a 10.5 GB workspace (0.24 s of hipMalloc, profiles/r01_malloc_probe.txt) into 5.2 GB (0.3 ms).
-        const uint64_t block_ints = 256 * ((affine || nwdist) ? 2 : 1);
+        const uint64_t block_ints = 256 * hand_vals;
         const uint64_t second = (max_strips > 2 || b->paired) ? half : block_ints;
         {   // very long texts: fewer workgroups rather than a workspace that does not fit (tasks come off a queue,
             // any grid is correct)

@@ -43,8 +43,13 @@ def test_distance_reference_fixtures(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("alphabet", [b"ACGT", b"AC", bytes(range(65, 91)), bytes(range(1, 256))])
-def test_distance_random_batches_match_oracle(ctx, alphabet):
+def test_distance_random_batches_match_oracle(ctx, alphabet, packed, monkeypatch):
+    """both forms of the kernel: (H, dist) packed into one int32 key (the default while dist < 2^12 and H fits 18 bits;
+    the scoring 100/-90/-70 does not and takes the plain form by itself) and the plain two-value form (forced)."""
+    if not packed:
+        monkeypatch.setenv("PWA_NO_PACKED_DIST", "1")
     rng = random.Random(len(alphabet) + 7)
     lens = [0, 1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, 300]
     seqs = [bytes(rng.choice(alphabet) for _ in range(rng.choice(lens) if rng.random() < 0.5 else rng.randint(1, 260)))
@@ -56,6 +61,23 @@ def test_distance_random_batches_match_oracle(ctx, alphabet):
         want = [O.nw_distance(seqs[a], seqs[b], *sc)[0] for a, b in zip(pa, pb)]
         bad = [k for k in range(500) if got[k] != want[k]]
         assert not bad, (sc, [(len(seqs[pa[k]]), len(seqs[pb[k]]), got[k], want[k]) for k in bad[:5]])
+
+
+@pytest.mark.gpu
+def test_distance_long_sequences_leave_the_packed_form(ctx):
+    """n + m > 4000: distances no longer fit the key's 12 bits; 1000 x 1000 sits inside.  Both against the oracle."""
+    seqs = [O.gen(4, 2, i, n) for i, n in enumerate([1000, 1000, 999, 2500, 2400, 1700])]
+    pa = [0, 0, 1, 3, 3, 4, 0]
+    pb = [1, 2, 2, 4, 5, 5, 3]
+    for sc in [(1, -1, -1), (5, -4, -4)]:
+        b = ctx.batch_distances(seqs[:3], [0, 0, 1], [1, 2, 2], *sc)
+        assert "PACKED" in b.info()["kernel"]
+        b.close()
+        b = ctx.batch_distances(seqs, pa, pb, *sc)
+        assert "PACKED" not in b.info()["kernel"]
+        b.close()
+        got = ctx.distances(seqs, pa, pb, *sc)
+        assert got == [O.nw_distance(seqs[a], seqs[c], *sc)[0] for a, c in zip(pa, pb)], sc
 
 
 @pytest.mark.gpu
