@@ -49,6 +49,19 @@ VALU_PER_CELL = {"SC_PERM": 10.75, "SC_CMP": 12.0, "PACKED": 7.47,   # batch_nwd
                  "BM_NWG,SC_PERM": 2.53, "BM_NWG,SC_CMP": 4.5}
 
 
+# Issue cost of the column loop per cell and SIMD lane group, from the per-instruction costs measured by
+# tools/valu_class.hip (profiles/r01_valu_class_microbench.txt, >= 2 waves per SIMD): add / sub(+clamp) / and / xor / mov
+# 3.15 / 3.16 / 2.68 / 2.65 / 2.64 cycles, max / max3 / sdwa / perm / cmp / cndmask ~4.45.  The flat "4 cycles per
+# instruction" of VALU_PEAK_TOPS is the mean of the two classes; this is the finer model.
+ISSUE_CYCLES_PER_CELL = {
+    "BM_SWS,SC_PERM": 4.45 + 1.5 * 4.46 + 3.16 + 0.25 * 4.49 + 0.25 * 2.65,          # sdwa add, 1.5 max3, sub clamp, table
+    "BM_SWS,SC_PERM,LANES": 4.45 + 1.5 * 4.46 + 3.16 + (0.25 + 4 / 304) * 4.49 + 0.25 * 2.65,
+    "BM_NWG,SC_PERM": 4.45 + 4.46 + 0.25 * 4.49 + 0.25 * 2.65,                       # sdwa add, max3, table
+    "BM_NWG,SC_PERM,LANES": 4.45 + 4.46 + (0.25 + 4 / 608) * 4.49 + 0.25 * 2.65,
+    "PACKED": 3 * 3.15 + 2.68 + 4.45 + 4.45 + 4.46,                                   # 3 add, and, cmp, cndmask, max3
+}
+
+
 def load_pkg():
     name = "bioinformatics_algorithms_amd"
     if name in sys.modules:
@@ -353,6 +366,11 @@ def main():
         "unit": "Tiop/s",
         "frac": ((padded / (k_ms * 1e-3)) * ops / 1e12) / VALU_PEAK_TOPS if ops else None,
         "valu_ops_per_cell": ops,
+        "issue_model": ({"cycles_per_cell_model": ISSUE_CYCLES_PER_CELL[key],
+                         "cycles_per_cell_measured": (k_ms * 1e-3) * 2.4e9 * 1024 / (padded / 64.0),
+                         "frac": ISSUE_CYCLES_PER_CELL[key] / ((k_ms * 1e-3) * 2.4e9 * 1024 / (padded / 64.0)),
+                         "source": "profiles/r01_valu_class_microbench.txt (per-instruction issue costs, 2.4 GHz nominal)"}
+                        if key in ISSUE_CYCLES_PER_CELL else None),
         "kernel_ms": k_ms,
         "kernel_gcups": kernel_gcups,
         "padded_cells_per_launch": padded,
