@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s 
 VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 # VALU instructions per evaluated DP cell of each instantiation: SQ_INSTS_VALU x 64 / padded cells from the
 # rocprofv3 PMC pass (c3: 5.02, c4: 2.53; profiles/), the others counted in the gfx950 ISA of the column block
-VALU_PER_CELL = {"SC_PERM": 10.75, "SC_CMP": 12.0, "PACKED": 7.47,   # batch_nwdist_kernel<R,SCORE> / packed keys (hw4)
+VALU_PER_CELL = {"SC_PERM": 10.75, "SC_CMP": 12.0, "PACKED": 7.03,   # batch_nwdist_kernel<R,SCORE> / packed keys (hw4)
                  "BM_AFFS,SC_PERM": 5.6, "BM_AFFS,SC_CMP": 7.6, "BM_AFF,SC_PERM": 7.6, "BM_AFF,SC_CMP": 9.6,
                  "BM_SWS,SC_PERM": 4.06, "BM_SWS,SC_CMP": 6.06,
                  "BM_SWS,SC_PERM,LANES": 4.11, "BM_SWS,SC_CMP,LANES": 5.6,   # per-lane texts: 1248 / 1702 VALU per 304 cells (ISA)
