@@ -718,7 +718,10 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             const int R = e.R;
             if (force && std::atoi(force) != R) continue;
             if (force_mode && std::atoi(force_mode) != e.mode) continue;
-            const long double w = e.mode == BM_SWS ? 4.06L : (e.mode == BM_SW ? 5.02L : 1.0L);   // VALU per cell
+            long double w = e.mode == BM_SWS ? 4.06L : (e.mode == BM_SW ? 5.02L : 1.0L);   // VALU per cell
+            // affine strips of more than 40 rows run 2 instead of 3 waves per SIMD: [gpu] all pairs of 1024 x 1000 take
+            // 93.2 ms at R = 52 against 89.2 ms at R = 32 for the same padded cells
+            if ((e.mode == BM_AFF || e.mode == BM_AFFS) && R > 40) w *= 1.045L;
             // evaluated cells + the strip hand-off priced at ~2 cells per column and strip boundary ([gpu]: the
             // 1000-row affine pass is equally fast at R = 32 and 52 but moves 37 % fewer HBM bytes at 52)
             long double cost = 0;
