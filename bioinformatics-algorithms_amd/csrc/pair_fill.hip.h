@@ -38,7 +38,26 @@
 
 namespace pwa {
 
-enum { TB_STOP = 0, TB_DIAG = 1, TB_UP = 2, TB_LEFT = 3 };
+// Traceback codes = the direction's PRIORITY in the reference's tie-break, so that they can ride in the two low bits
+// of a packed key (see stripe_step): global (hw2.cpp:142-153) prefers diag, then left, then up; local (211-222)
+// prefers the zero floor, then diag, then up, then left.
+enum { TB_DIAG = 2, TB_STOP = 3 };
+template <bool LOCAL> struct TbCode {
+    static constexpr int UP = LOCAL ? 1 : 0, LEFT = LOCAL ? 0 : 1;
+};
+// Keyed form of a DP value (traceback kernels): key = H * 4 + priority.  One v_max3 over the three candidate keys picks
+// the maximum AND, among equal scores, the direction the reference prefers; its low bits are the traceback code.
+// A cell is kept as  stored(H) = H * 4 + (gap * 4 + prio(left)),  i.e. the candidate its RIGHT neighbour sees.
+// codes byte R = key & 3, in one instruction: SDWA writes a single byte of the destination and keeps the rest
+template <int R>
+__device__ __forceinline__ void tb_put_code(uint32_t& codes, int key) {
+    static_assert(R >= 0 && R < 4, "four rows per code dword");
+    if (R == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(codes) : "v"(key), "v"(3));
+    if (R == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(codes) : "v"(key), "v"(3));
+    if (R == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(codes) : "v"(key), "v"(3));
+    if (R == 3) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(codes) : "v"(key), "v"(3));
+}
+__device__ __forceinline__ int tb_stored(int h, int gap, int prio_left) { return (int)((unsigned)h * 4u + (unsigned)gap * 4u + (unsigned)prio_left); }
 
 struct PairResult {
     int32_t score;
@@ -140,32 +159,62 @@ __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i
     if (active) {
         const int j = c + 1;
         int dg = diag0, up = up_in;
+        if (TB) {
+            // keyed form: candidates are built with fast-class adds, ONE v_max3 replaces the two compare-and-select
+            // chains for the value and for the code (costs per instruction: profiles/r01_valu_class_microbench.txt)
+            // the caller passes the three key constants in place of the scores (wave-uniform, computed once per task):
+            // match -> (match - gap) * 4 + (prio(diag) - prio(left)), mismatch likewise, gap -> gap * 4 + prio(left)
+            constexpr int PU = TbCode<LOCAL>::UP, PL = TbCode<LOCAL>::LEFT;
+            const int cdm = match, cdx = mismatch, cl = gap;
 #pragma unroll
-        for (int r = 0; r < RL; ++r) {
-            const int sc = (pc[r] == tch) ? match : mismatch;
-            const int tdiag = p_addw(dg, sc);
-            const int lf = hl[r];
-            const int ug = p_addw(up, gap), lg = p_addw(lf, gap);
-            int h, code;
-            if (LOCAL) {
-                h = max(0, max(tdiag, max(ug, lg)));                                                   // hw2.cpp:211
-                code = (h == 0) ? TB_STOP : (h == tdiag) ? TB_DIAG : (h == ug) ? TB_UP : TB_LEFT;      // 214-222
-                if (h > bs[r]) {                                                                       // 225-229
-                    bs[r] = h;
-                    bj[r] = j;
+            for (int r = 0; r < RL; ++r) {
+                const int kd = p_addw(dg, (pc[r] == tch) ? cdm : cdx);   // hw2.cpp:142 / 208-211: diag + s
+                const int ku = p_addw(up, PU - PL);                       // up + gap
+                const int kl = hl[r];                                     // left + gap
+                int k = max(kd, max(ku, kl));
+                if (LOCAL) k = max(k, (int)TB_STOP);                      // the zero floor wins every tie (hw2.cpp:214)
+                const int base = k & ~3;
+                if (LOCAL) {
+                    if (base > bs[r]) {                                   // 225-229 (bs holds H * 4)
+                        bs[r] = base;
+                        bj[r] = j;
+                    }
+                } else if (EDGE && (i_first + r) == n && j == m) {
+                    res->score = k >> 2;                                  // 186
                 }
-            } else {
-                h = tdiag;                                                                             // 142-153
-                code = TB_DIAG;
-                if (lg > h) { h = lg; code = TB_LEFT; }
-                if (ug > h) { h = ug; code = TB_UP; }
-                if (EDGE && (i_first + r) == n && j == m) res->score = h;                              // 186
+                if (r == 0) tb_put_code<0>(codes, k);
+                if (r == 1) tb_put_code<1>(codes, k);
+                if (r == 2) tb_put_code<2>(codes, k);
+                if (r == 3) tb_put_code<3>(codes, k);
+                const int l = p_addw(base, cl);
+                dg = kl;
+                up = l;
+                hl[r] = l;
+                hnew[r] = SBAND ? (k >> 2) : 0;
             }
-            codes |= (uint32_t)code << (8 * r);
-            dg = lf;
-            up = h;
-            hl[r] = h;
-            hnew[r] = h;
+        } else {
+#pragma unroll
+            for (int r = 0; r < RL; ++r) {
+                const int sc = (pc[r] == tch) ? match : mismatch;
+                const int tdiag = p_addw(dg, sc);
+                const int lf = hl[r];
+                const int ug = p_addw(up, gap), lg = p_addw(lf, gap);
+                int h;
+                if (LOCAL) {
+                    h = max(0, max(tdiag, max(ug, lg)));                                                   // hw2.cpp:211
+                    if (h > bs[r]) {                                                                       // 225-229
+                        bs[r] = h;
+                        bj[r] = j;
+                    }
+                } else {
+                    h = max(tdiag, max(lg, ug));                                                           // 142-153
+                    if (EDGE && (i_first + r) == n && j == m) res->score = h;                              // 186
+                }
+                dg = lf;
+                up = h;
+                hl[r] = h;
+                hnew[r] = h;
+            }
         }
         diag0 = up_in;
         bottom = up;
@@ -259,6 +308,7 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                             int v;
                             if (top_global) v = __hip_atomic_load(rin + c, PWA_RLX_AGENT);   // sc1: issued after the poll's value is known
                             else v = LOCAL ? 0 : p_mulw(c + 1, gap);                         // dp[0][j], hw2.cpp:131-136
+                            if (TB && !top_global) v = tb_stored(v, gap, TbCode<LOCAL>::LEFT);
                             sh.ring[0][c % kRing] = v;
                             sh.text[c % kTRing] = txt[c];
                         }
@@ -301,13 +351,19 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                 const int i = i_first + r;
                 pc[r] = (i <= n) ? (int)((g_cu8*)P.pat)[i - 1] : 256;   // 256 never equals a text byte
                 hl[r] = LOCAL ? 0 : p_mulw(i, gap);                     // dp[i][0], hw2.cpp:125-130
+                if (TB) hl[r] = tb_stored(hl[r], gap, TbCode<LOCAL>::LEFT);
                 bs[r] = 0;
                 bj[r] = 0;
             }
             int diag0 = LOCAL ? 0 : p_mulw(i_first - 1, gap);           // dp[i_first-1][0]
+            if (TB) diag0 = tb_stored(diag0, gap, TbCode<LOCAL>::LEFT);
             g_u8* tbs = TB ? (g_u8*)(P.tb + (size_t)s * T * 64 * RL) : nullptr;
             g_i32* sbs = SBAND ? (g_i32*)(P.sband + (size_t)s * T * 64 * RL) : nullptr;
             PWA_GLOBAL PairResult* res = (PWA_GLOBAL PairResult*)P.res;
+            // traceback kernels: stripe_step takes the key constants instead of the three scores
+            const int a_match = TB ? (int)(((unsigned)match - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - TbCode<LOCAL>::LEFT)) : match;
+            const int a_mismatch = TB ? (int)(((unsigned)mismatch - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - TbCode<LOCAL>::LEFT)) : mismatch;
+            const int a_gap = TB ? (int)((unsigned)gap * 4u + (unsigned)TbCode<LOCAL>::LEFT) : gap;
             int* rin = sh.ring[wave];
             int* rout = sh.ring[wave + 1];
             int bottom = 0, tch = 0, coll = 0;
@@ -332,13 +388,13 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
 #pragma unroll PWA_STEP_UNROLL
                     for (int q = 0; q < CH; ++q)
                         stripe_step<RL, LOCAL, TB, SBAND, false>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
-                                                                 tcv, coll, bs, bj, match, mismatch, gap, tbs, sbs, res);
+                                                                 tcv, coll, bs, bj, a_match, a_mismatch, a_gap, tbs, sbs, res);
                 } else {
                     const int qn = min(CH, T - t0);
 #pragma unroll 1
                     for (int q = 0; q < qn; ++q)
                         stripe_step<RL, LOCAL, TB, SBAND, true>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
-                                                                tcv, coll, bs, bj, match, mismatch, gap, tbs, sbs, res);
+                                                                tcv, coll, bs, bj, a_match, a_mismatch, a_gap, tbs, sbs, res);
 #pragma unroll 1
                     for (int q = qn; q < CH; ++q) coll = wave_shl1(bottom, coll);   // keep the collector aligned
                 }
@@ -378,7 +434,7 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                 }
                 if (lane == 0) {
                     g_i32* bp = (g_i32*)(G.best + P.first_stripe + s);
-                    bp[0] = s_best;
+                    bp[0] = TB ? (s_best >> 2) : s_best;   // the traceback kernels track H * 4
                     bp[1] = i_best;
                     bp[2] = j_best;
                     bp[3] = 0;
@@ -515,12 +571,12 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         j -= L;
         if (L < 64) {
             const int c2 = __builtin_amdgcn_readlane(code, L);
-            if (c2 == TB_UP) {                                           // hw2.cpp:170-174 / 246-250
+            if (c2 == TbCode<LOCAL>::UP) {                               // hw2.cpp:170-174 / 246-250
                 if (OPS && lane == 0) ops[cnt] = 'D';
                 ++cnt;
                 --i;
                 run = 0;
-            } else if (c2 == TB_LEFT) {                                  // hw2.cpp:175-179 / 251-255
+            } else if (c2 == TbCode<LOCAL>::LEFT) {                      // hw2.cpp:175-179 / 251-255
                 if (OPS && lane == 0) ops[cnt] = 'I';
                 ++cnt;
                 --j;

@@ -111,6 +111,13 @@ void for_seq_ranges(const uint64_t* seq_off, uint32_t n_seq, F&& fn, int* n_thre
     for (auto& x : th) x.join();
 }
 
+// The traceback kernels keep H * 4 + priority in int32 (pair_fill.hip.h): |H| has to stay below 2^28.
+bool tb_range_ok(uint64_t n_plus_m, int match, int mismatch, int gap) {
+    const uint64_t amax = (uint64_t)std::max<int64_t>({std::llabs((long long)match), std::llabs((long long)mismatch),
+                                                       std::llabs((long long)gap), 1});
+    return (n_plus_m + 2) <= (1ull << 28) / amax;
+}
+
 int fail(pwa_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
     return code;
@@ -1380,8 +1387,13 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     }
     mark("arena upload");
 
-    uint64_t longest_n = 0;
-    for (uint64_t k = 0; k < n_pairs; ++k) longest_n = std::max(longest_n, slen(pair_a[k]));
+    uint64_t longest_n = 0, longest_sum = 0;
+    for (uint64_t k = 0; k < n_pairs; ++k) {
+        longest_n = std::max(longest_n, slen(pair_a[k]));
+        longest_sum = std::max(longest_sum, slen(pair_a[k]) + slen(pair_b[k]));
+    }
+    if (!tb_range_ok(longest_sum, match, mismatch, gap))
+        return fail(ctx, PWA_E_CAPACITY, "scores times lengths exceed 2^28: outside the traceback engine's packed keys");
     const PairGeom geom = choose_geom(longest_n);
     auto tb_band_bytes = [&](uint64_t n, uint64_t m) { return ::tb_band_bytes(n, m, geom.rl); };
     // pairs are processed in chunks whose traceback bands fit the free HBM
@@ -1568,6 +1580,8 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     if (mode != PWA_MODE_NW && mode != PWA_MODE_SW) return fail(ctx, PWA_E_INVALID, "unknown mode");
     if ((n && !pattern) || (m && !text) || (!dp_out && !tb_out)) return fail(ctx, PWA_E_INVALID, "null input");
     if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
+    if (!tb_range_ok(n + m, match, mismatch, gap))
+        return fail(ctx, PWA_E_CAPACITY, "scores times lengths exceed 2^28: outside the traceback engine's packed keys");
     const bool local = mode == PWA_MODE_SW;
     const uint64_t W = m + 1;
     // row 0 and column 0 exactly as the reference initialises them (hw2.cpp:119-136 / 193-194)
@@ -1614,7 +1628,9 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     std::vector<int32_t> hs(dp_out ? band : 0);
     if (tb_out) HIPC(ctx, hipMemcpy(hb.data(), d_band.p, band, hipMemcpyDeviceToHost));
     if (dp_out) HIPC(ctx, hipMemcpy(hs.data(), d_sband.p, band * sizeof(int32_t), hipMemcpyDeviceToHost));
-    static const char kCode[4] = {'0', 'd', 'u', 'l'};   // hw2.cpp:214-222 / 145-153
+    // band codes are tie-break priorities (pair_fill.hip.h): global up 0, left 1, diag 2; local left 0, up 1, diag 2, floor 3
+    static const char kCodeNW[4] = {'u', 'l', 'd', 'd'}, kCodeSW[4] = {'l', 'u', 'd', '0'};   // hw2.cpp:145-153 / 214-222
+    const char* const kCode = local ? kCodeSW : kCodeNW;
     const uint64_t T = m + 63;
     for (uint64_t i = 1; i <= n; ++i) {
         const uint64_t q = i - 1, st = q / (64 * kRL), k = (q % (64 * kRL)) / kRL, r = q % kRL;
