@@ -1,0 +1,32 @@
+// pair_kernels.hip -- every instantiation of the wavefront (pair) engine: fill kernels and traceback walks.
+// Own translation unit: compiles next to pwalign.hip and strip_kernels.hip.
+#include "kernel_table.h"
+
+namespace pwa {
+
+template <int RL, int W>
+static pair_kernel_t pair_fill_pick(bool local, bool tb, bool sband) {
+    if (local) {
+        if (tb) return sband ? pair_fill_kernel<RL, W, true, true, true> : pair_fill_kernel<RL, W, true, true, false>;
+        return pair_fill_kernel<RL, W, true, false, false>;
+    }
+    if (tb) return sband ? pair_fill_kernel<RL, W, false, true, true> : pair_fill_kernel<RL, W, false, true, false>;
+    return pair_fill_kernel<RL, W, false, false, false>;
+}
+pair_kernel_t pair_fill_kernel_for(int rl, int w, bool local, bool tb, bool sband) {
+    if (rl == 2) return w == 1 ? pair_fill_pick<2, 1>(local, tb, sband) : pair_fill_pick<2, 4>(local, tb, sband);
+    return w == 1 ? pair_fill_pick<4, 1>(local, tb, sband) : pair_fill_pick<4, 4>(local, tb, sband);
+}
+template <int RL>
+static pair_kernel_t pair_tb_pick(bool local, int walk) {
+    if (local)
+        return walk == WALK_OPS ? pair_traceback_kernel<RL, true, WALK_OPS>
+               : walk == WALK_OVERLAP ? pair_traceback_kernel<RL, true, WALK_OVERLAP> : pair_traceback_kernel<RL, true, WALK_NONE>;
+    return walk == WALK_OPS ? pair_traceback_kernel<RL, false, WALK_OPS>
+           : walk == WALK_OVERLAP ? pair_traceback_kernel<RL, false, WALK_OVERLAP> : pair_traceback_kernel<RL, false, WALK_NONE>;
+}
+pair_kernel_t pair_traceback_kernel_for(int rl, bool local, int walk) {
+    return rl == 2 ? pair_tb_pick<2>(local, walk) : pair_tb_pick<4>(local, walk);
+}
+
+}  // namespace pwa

@@ -17,11 +17,8 @@
 #include <thread>
 #include <vector>
 
-#include "batch_scores.hip.h"
-#include "batch_affine.hip.h"
+#include "kernel_table.h"
 #include "batch_affine_tb.hip.h"
-#include "batch_nwdist.hip.h"
-#include "pair_fill.hip.h"
 
 using namespace pwa;
 
@@ -136,65 +133,9 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 inline int32_t wrap_mul(int64_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
 
-// --------------------------------------------------------------------------- kernel tables
-typedef void (*batch_kernel_t)(const BatchParams);
-typedef void (*affine_kernel_t)(const AffineParams);
-typedef void (*nwdist_kernel_t)(const NwDistParams);
-enum { BM_AFF = 3, BM_AFFS = 4, BM_DIST = 5, BM_DISTP = 7 };   // (6 = BM_SWS, batch_scores.hip.h); 7: packed-key hw4 form   // affine (hw3) plain / shifted, hw4 NW + distance; 0..2: batch_scores.hip.h
-struct BatchKernelEntry {
-    int R, mode, score;
-    batch_kernel_t fn;       // multi-strip form (strip hand-off rows through HBM)
-    const char* name;
-    affine_kernel_t afn = nullptr;
-    nwdist_kernel_t dfn = nullptr;
-    batch_kernel_t fn_single = nullptr;   // every task a single strip: no hand-off accesses at all
-    batch_kernel_t fn_pair = nullptr;     // every task at most two strips: two waves per task, hand-off through an LDS ring
-    batch_kernel_t fn_lanes = nullptr;         // every lane its own text (index-paired lists), multi-strip
-    batch_kernel_t fn_lanes_single = nullptr;  // ... every task a single strip
-};
-#define BK(R, M, S) {R, M, S, batch_scores_kernel<R, M, S, true>, "batch_scores_kernel<R=" #R "," #M "," #S ">", nullptr, nullptr, \
-                     batch_scores_kernel<R, M, S, false>}
-#define BKP(R, M, S) {R, M, S, batch_scores_kernel<R, M, S, true>, "batch_scores_kernel<R=" #R "," #M "," #S ">", nullptr, nullptr, \
-                      batch_scores_kernel<R, M, S, false>, batch_scores_pair_kernel<R, M, S>, \
-                      batch_scores_kernel<R, M, S, true, true>, batch_scores_kernel<R, M, S, false, true>}
-#define BKL(R, M, S) {R, M, S, batch_scores_kernel<R, M, S, true>, "batch_scores_kernel<R=" #R "," #M "," #S ">", nullptr, nullptr, \
-                      batch_scores_kernel<R, M, S, false>, nullptr, \
-                      batch_scores_kernel<R, M, S, true, true>, batch_scores_kernel<R, M, S, false, true>}
-const BatchKernelEntry kBatchKernels[] = {
-    BK(76, BM_SW, SC_PERM),   BK(104, BM_SW, SC_PERM),
-    BKL(40, BM_SWS, SC_PERM), BKP(52, BM_SWS, SC_PERM), BKP(76, BM_SWS, SC_PERM), BKL(96, BM_SWS, SC_PERM),   // R=96 paired spills in the column loop
-    BKL(40, BM_SWS, SC_CMP),  BKP(52, BM_SWS, SC_CMP),  BKP(76, BM_SWS, SC_CMP),  BKP(96, BM_SWS, SC_CMP),
-    BK(64, BM_SW, SC_PERM),   BK(128, BM_SW, SC_PERM),  BK(152, BM_SW, SC_PERM),
-    BK(64, BM_SW, SC_CMP),    BK(128, BM_SW, SC_CMP),   BK(152, BM_SW, SC_CMP),
-    BK(64, BM_NW, SC_PERM),   BK(128, BM_NW, SC_PERM),  BK(152, BM_NW, SC_PERM),
-    BK(64, BM_NW, SC_CMP),    BK(128, BM_NW, SC_CMP),   BK(152, BM_NW, SC_CMP),
-    BKL(64, BM_NWG, SC_PERM), BKL(128, BM_NWG, SC_PERM), BKL(152, BM_NWG, SC_PERM),
-    BK(64, BM_NWG, SC_CMP),   BK(128, BM_NWG, SC_CMP),  BK(152, BM_NWG, SC_CMP),
-#define AK(R, M, S, SH) {R, M, S, nullptr, "batch_affine_kernel<R=" #R "," #M "," #S ">", batch_affine_kernel<R, S, SH>}
-    AK(32, BM_AFFS, SC_PERM, true),  AK(52, BM_AFFS, SC_PERM, true),  AK(32, BM_AFFS, SC_CMP, true),  AK(52, BM_AFFS, SC_CMP, true),
-    AK(32, BM_AFF, SC_PERM, false),  AK(52, BM_AFF, SC_PERM, false),  AK(32, BM_AFF, SC_CMP, false),  AK(52, BM_AFF, SC_CMP, false),
-#undef AK
-#define DK(R, S) {R, BM_DIST, S, nullptr, "batch_nwdist_kernel<R=" #R "," #S ">", nullptr, batch_nwdist_kernel<R, S>}
-    DK(32, SC_PERM), DK(64, SC_PERM), DK(32, SC_CMP), DK(64, SC_CMP),
-#define DKP(R, S) {R, BM_DISTP, S, nullptr, "batch_nwdist_kernel<R=" #R ",PACKED>", nullptr, batch_nwdist_packed_kernel<R>}
-    DKP(64, SC_PERM), DKP(128, SC_PERM), DKP(64, SC_CMP), DKP(128, SC_CMP),   // one compare-based kernel for both codings
-#undef DKP
-#undef DK
-};
-#undef BK
-#undef BKP
-#undef BKL
-
-const BatchKernelEntry* find_batch_kernel(int R, int mode, int score) {
-    for (const auto& e : kBatchKernels)
-        if (e.R == R && e.mode == mode && e.score == score) return &e;
-    return nullptr;
-}
-
 // Geometry of the wavefront (pair) engine: RL rows per lane (stripe = 64*RL rows) and W compute waves
 // per workgroup (a workgroup task = W consecutive stripes + one helper wave).  Pairs of a single
 // stripe use W = 1; short multi-stripe pairs get RL = 2 (twice the stripes = twice the waves in flight).
-typedef void (*pair_kernel_t)(const PairParams);
 struct PairGeom {
     int rl, w;
 };
@@ -208,30 +149,8 @@ PairGeom choose_geom(uint64_t max_n) {
     if (const char* e = std::getenv("PWA_FORCE_W")) g.w = std::atoi(e) == 1 ? 1 : 4;
     return g;
 }
-template <int RL, int W>
-pair_kernel_t pair_fill_pick(bool local, bool tb, bool sband) {
-    if (local) {
-        if (tb) return sband ? pair_fill_kernel<RL, W, true, true, true> : pair_fill_kernel<RL, W, true, true, false>;
-        return pair_fill_kernel<RL, W, true, false, false>;
-    }
-    if (tb) return sband ? pair_fill_kernel<RL, W, false, true, true> : pair_fill_kernel<RL, W, false, true, false>;
-    return pair_fill_kernel<RL, W, false, false, false>;
-}
-pair_kernel_t pair_fill_fn(PairGeom g, bool local, bool tb, bool sband) {
-    if (g.rl == 2) return g.w == 1 ? pair_fill_pick<2, 1>(local, tb, sband) : pair_fill_pick<2, 4>(local, tb, sband);
-    return g.w == 1 ? pair_fill_pick<4, 1>(local, tb, sband) : pair_fill_pick<4, 4>(local, tb, sband);
-}
-template <int RL>
-pair_kernel_t pair_tb_pick(bool local, int walk) {   // walk: WALK_NONE / WALK_OPS / WALK_OVERLAP
-    if (local)
-        return walk == WALK_OPS ? pair_traceback_kernel<RL, true, WALK_OPS>
-               : walk == WALK_OVERLAP ? pair_traceback_kernel<RL, true, WALK_OVERLAP> : pair_traceback_kernel<RL, true, WALK_NONE>;
-    return walk == WALK_OPS ? pair_traceback_kernel<RL, false, WALK_OPS>
-           : walk == WALK_OVERLAP ? pair_traceback_kernel<RL, false, WALK_OVERLAP> : pair_traceback_kernel<RL, false, WALK_NONE>;
-}
-pair_kernel_t pair_tb_fn(PairGeom g, bool local, int walk) {
-    return g.rl == 2 ? pair_tb_pick<2>(local, walk) : pair_tb_pick<4>(local, walk);
-}
+pair_kernel_t pair_fill_fn(PairGeom g, bool local, bool tb, bool sband) { return pair_fill_kernel_for(g.rl, g.w, local, tb, sband); }
+pair_kernel_t pair_tb_fn(PairGeom g, bool local, int walk) { return pair_traceback_kernel_for(g.rl, local, walk); }
 
 size_t tb_band_bytes(uint64_t n, uint64_t m, int rl) {
     const uint64_t stripes = (n + 64 * rl - 1) / (64 * rl);
@@ -678,7 +597,9 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         // instead (LANES kernels, local alignment only).  Pairs are sorted so that a wave's 64 pairs need about
         // the same number of strips and columns; a wave runs max(strips) x max(columns) of its lanes.
         bool kernels_have_lanes = false;
-        for (const auto& e : kBatchKernels) kernels_have_lanes |= (e.fn_lanes != nullptr && e.score == score_path);
+        size_t n_kernels = 0;
+        const BatchKernelEntry* const kernels = batch_kernel_table(&n_kernels);
+        for (size_t ki = 0; ki < n_kernels; ++ki) kernels_have_lanes |= (kernels[ki].fn_lanes != nullptr && kernels[ki].score == score_path);
         const bool text_pad_ok = score_path == SC_PERM ? n_alpha <= 6 : text_pad_byte >= 0;
         const bool underfilled = ht.size() * 64 > order.size() * 3 / 2 + 64;
         b->lanes = kmode == BM_SW && !affine && !nwdist && kernels_have_lanes && text_pad_ok && underfilled &&
@@ -717,7 +638,8 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         long double best_cost = -1;
         const char* force = std::getenv("PWA_FORCE_R");      // experiments only
         const char* force_mode = std::getenv("PWA_FORCE_MODE");
-        for (const auto& e : kBatchKernels) {
+        for (size_t ki = 0; ki < n_kernels; ++ki) {
+            const BatchKernelEntry& e = kernels[ki];
             // SW has two forms: BM_SW (R registers per lane, 5.0 VALU per cell) and BM_SWS (2R registers, 4.06)
             const bool mode_ok = e.mode == kmode || (kmode == BM_SW && e.mode == BM_SWS);
             if (!mode_ok || e.score != score_path) continue;
