@@ -143,7 +143,7 @@ __device__ __forceinline__ size_t tb_index(int i, int j, int m) {   // i, j >= 1
 
 // One anti-diagonal step of a stripe.  EDGE = some lanes of this step may lie outside the matrix
 // or compute the matrix's last column.
-template <int RL, bool LOCAL, bool TB, bool SBAND, bool EDGE>
+template <int RL, bool LOCAL, bool TB, bool SBAND, bool EDGE, bool PERM = false>
 __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i_first, const int (&pc)[RL], int (&hl)[RL],
                                             int& diag0, int& bottom, int& tch, int& topv, int& tcv, int& coll,
                                             int (&bs)[RL], int (&bj)[RL], int match, int mismatch, int gap,
@@ -166,9 +166,15 @@ __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i
             // match -> (match - gap) * 4 + (prio(diag) - prio(left)), mismatch likewise, gap -> gap * 4 + prio(left)
             constexpr int PU = TbCode<LOCAL>::UP, PL = TbCode<LOCAL>::LEFT;
             const int cdm = match, cdx = mismatch, cl = gap;
+            // PERM (sequences coded 0..6, pad 7): pc[0] holds the lane's RL codes as bytes, tch arrives splatted, and
+            // `match` / `mismatch` carry the byte table (selector 0 -> cdm, 1..7 -> cdx): one v_xor + one v_perm per
+            // step and a sign-extending SDWA add per row instead of compare + select + add per row
+            uint32_t s4 = 0;
+            if (PERM) s4 = __builtin_amdgcn_perm((uint32_t)mismatch, (uint32_t)match, (uint32_t)pc[0] ^ (uint32_t)tch);
 #pragma unroll
             for (int r = 0; r < RL; ++r) {
-                const int kd = p_addw(dg, (pc[r] == tch) ? cdm : cdx);   // hw2.cpp:142 / 208-211: diag + s
+                const int kd = PERM ? p_addw(dg, (int)(int8_t)(s4 >> (8 * r)))
+                                    : p_addw(dg, (pc[r] == tch) ? cdm : cdx);   // hw2.cpp:142 / 208-211: diag + s
                 const int ku = p_addw(up, PU - PL);                       // up + gap
                 const int kl = hl[r];                                     // left + gap
                 int k = max(kd, max(ku, kl));
@@ -256,8 +262,9 @@ struct WgShared {
     uint32_t task;
 };
 
-template <int RL, int W, bool LOCAL, bool TB, bool SBAND>
+template <int RL, int W, bool LOCAL, bool TB, bool SBAND, bool PERM = false>
 __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParams G) {
+    static_assert(!PERM || TB, "table scoring exists for the keyed (traceback) form only");
     constexpr int CH = kCH;
     __shared__ WgShared<W> sh;
     const int lane = threadIdx.x & 63;
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
 #pragma unroll
             for (int r = 0; r < RL; ++r) {
                 const int i = i_first + r;
-                pc[r] = (i <= n) ? (int)((g_cu8*)P.pat)[i - 1] : 256;   // 256 never equals a text byte
+                pc[r] = (i <= n) ? (int)((g_cu8*)P.pat)[i - 1] : (PERM ? 7 : 256);   // 256 / code 7 never equal a text symbol
                 hl[r] = LOCAL ? 0 : p_mulw(i, gap);                     // dp[i][0], hw2.cpp:125-130
                 if (TB) hl[r] = tb_stored(hl[r], gap, TbCode<LOCAL>::LEFT);
                 bs[r] = 0;
@@ -361,9 +368,18 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
             g_i32* sbs = SBAND ? (g_i32*)(P.sband + (size_t)s * T * 64 * RL) : nullptr;
             PWA_GLOBAL PairResult* res = (PWA_GLOBAL PairResult*)P.res;
             // traceback kernels: stripe_step takes the key constants instead of the three scores
-            const int a_match = TB ? (int)(((unsigned)match - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - TbCode<LOCAL>::LEFT)) : match;
-            const int a_mismatch = TB ? (int)(((unsigned)mismatch - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - TbCode<LOCAL>::LEFT)) : mismatch;
+            int a_match = TB ? (int)(((unsigned)match - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - TbCode<LOCAL>::LEFT)) : match;
+            int a_mismatch = TB ? (int)(((unsigned)mismatch - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - TbCode<LOCAL>::LEFT)) : mismatch;
             const int a_gap = TB ? (int)((unsigned)gap * 4u + (unsigned)TbCode<LOCAL>::LEFT) : gap;
+            if (PERM) {   // ... or, coded sequences, the byte table built from them (the host checked that both fit a byte)
+                const uint32_t bm = (uint32_t)(uint8_t)(int8_t)a_match, bx = (uint32_t)(uint8_t)(int8_t)a_mismatch;
+                a_match = (int)(bm | (bx << 8) | (bx << 16) | (bx << 24));   // selectors 0..3
+                a_mismatch = (int)(bx * 0x01010101u);                        // selectors 4..7
+#pragma unroll
+                for (int r = 1; r < RL; ++r) pc[0] |= pc[r] << (8 * r);
+#pragma unroll
+                for (int r = RL; r < 4; ++r) pc[0] |= 7 << (8 * r);
+            }
             int* rin = sh.ring[wave];
             int* rout = sh.ring[wave + 1];
             int bottom = 0, tch = 0, coll = 0;
@@ -381,19 +397,20 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                 if (lane < CH && c0 < m) {
                     topv = rin[c0 % kRing];
                     tcv = sh.text[c0 % kTRing];
+                    if (PERM) tcv *= 0x01010101;   // the text symbol travels down the lanes already splatted
                 }
                 lds_post(&sh.taken[wave], need);
                 const bool interior = t0 >= 63 && t0 + CH < m;   // every lane inside the matrix, last column not touched
                 if (interior) {
 #pragma unroll PWA_STEP_UNROLL
                     for (int q = 0; q < CH; ++q)
-                        stripe_step<RL, LOCAL, TB, SBAND, false>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
+                        stripe_step<RL, LOCAL, TB, SBAND, false, PERM>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
                                                                  tcv, coll, bs, bj, a_match, a_mismatch, a_gap, tbs, sbs, res);
                 } else {
                     const int qn = min(CH, T - t0);
 #pragma unroll 1
                     for (int q = 0; q < qn; ++q)
-                        stripe_step<RL, LOCAL, TB, SBAND, true>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
+                        stripe_step<RL, LOCAL, TB, SBAND, true, PERM>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
                                                                 tcv, coll, bs, bj, a_match, a_mismatch, a_gap, tbs, sbs, res);
 #pragma unroll 1
                     for (int q = qn; q < CH; ++q) coll = wave_shl1(bottom, coll);   // keep the collector aligned

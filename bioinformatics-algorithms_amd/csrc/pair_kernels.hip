@@ -5,7 +5,11 @@
 namespace pwa {
 
 template <int RL, int W>
-static pair_kernel_t pair_fill_pick(bool local, bool tb, bool sband) {
+static pair_kernel_t pair_fill_pick(bool local, bool tb, bool sband, bool perm) {
+    if (tb && perm) {   // coded sequences: byte-table scoring
+        if (local) return sband ? pair_fill_kernel<RL, W, true, true, true, true> : pair_fill_kernel<RL, W, true, true, false, true>;
+        return sband ? pair_fill_kernel<RL, W, false, true, true, true> : pair_fill_kernel<RL, W, false, true, false, true>;
+    }
     if (local) {
         if (tb) return sband ? pair_fill_kernel<RL, W, true, true, true> : pair_fill_kernel<RL, W, true, true, false>;
         return pair_fill_kernel<RL, W, true, false, false>;
@@ -13,9 +17,9 @@ static pair_kernel_t pair_fill_pick(bool local, bool tb, bool sband) {
     if (tb) return sband ? pair_fill_kernel<RL, W, false, true, true> : pair_fill_kernel<RL, W, false, true, false>;
     return pair_fill_kernel<RL, W, false, false, false>;
 }
-pair_kernel_t pair_fill_kernel_for(int rl, int w, bool local, bool tb, bool sband) {
-    if (rl == 2) return w == 1 ? pair_fill_pick<2, 1>(local, tb, sband) : pair_fill_pick<2, 4>(local, tb, sband);
-    return w == 1 ? pair_fill_pick<4, 1>(local, tb, sband) : pair_fill_pick<4, 4>(local, tb, sband);
+pair_kernel_t pair_fill_kernel_for(int rl, int w, bool local, bool tb, bool sband, bool perm) {
+    if (rl == 2) return w == 1 ? pair_fill_pick<2, 1>(local, tb, sband, perm) : pair_fill_pick<2, 4>(local, tb, sband, perm);
+    return w == 1 ? pair_fill_pick<4, 1>(local, tb, sband, perm) : pair_fill_pick<4, 4>(local, tb, sband, perm);
 }
 template <int RL>
 static pair_kernel_t pair_tb_pick(bool local, int walk) {

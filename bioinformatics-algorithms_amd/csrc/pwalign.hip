@@ -149,7 +149,7 @@ PairGeom choose_geom(uint64_t max_n) {
     if (const char* e = std::getenv("PWA_FORCE_W")) g.w = std::atoi(e) == 1 ? 1 : 4;
     return g;
 }
-pair_kernel_t pair_fill_fn(PairGeom g, bool local, bool tb, bool sband) { return pair_fill_kernel_for(g.rl, g.w, local, tb, sband); }
+pair_kernel_t pair_fill_fn(PairGeom g, bool local, bool tb, bool sband, bool perm) { return pair_fill_kernel_for(g.rl, g.w, local, tb, sband, perm); }
 pair_kernel_t pair_tb_fn(PairGeom g, bool local, int walk) { return pair_traceback_kernel_for(g.rl, local, walk); }
 
 size_t tb_band_bytes(uint64_t n, uint64_t m, int rl) {
@@ -163,6 +163,7 @@ struct PairLaunch {
     DevBuf desc, tasks, rows, progress, best, queue;
     PairParams G{};
     PairGeom geom{4, 4};
+    bool perm = false;   // sequences are coded 0..6 (pad 7) and the key constants fit a byte: table-scoring fill kernels
     uint32_t grid = 0;
     uint64_t row_bytes = 0;
 
@@ -219,7 +220,7 @@ struct PairLaunch {
     int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, int walk, hipEvent_t after_fill, bool sband = false) {
         HIPC(ctx, hipMemsetAsync(queue.p, 0, 16, st));
         HIPC(ctx, hipMemsetAsync(progress.p, 0, progress.bytes, st));
-        hipLaunchKernelGGL(pair_fill_fn(geom, local, tb, sband), dim3(grid), dim3(64 * (geom.w + 1)), 0, st, G);
+        hipLaunchKernelGGL(pair_fill_fn(geom, local, tb, sband, perm && tb), dim3(grid), dim3(64 * (geom.w + 1)), 0, st, G);
         HIPC(ctx, hipGetLastError());
         if (after_fill) HIPC(ctx, hipEventRecord(after_fill, st));
         hipLaunchKernelGGL(pair_tb_fn(geom, local, walk), dim3(G.n_pairs), dim3(64), 0, st, G);   // one wave per pair
@@ -1299,11 +1300,37 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
             arena_bytes += align_up(slen(s) + 1, 16);
         }
     arena_bytes += 256;
+    // Alphabets of at most 7 symbols (DNA, DNA + N, ...) are stored as codes 0..6 -- equality is all the recurrence
+    // ever asks of a symbol (hw2.cpp:142, 208) -- so that the fill can score four rows with one byte-table lookup
+    // (pair_fill.hip.h, PERM).  The table holds the two diagonal key constants: both must fit a signed byte.
+    bool coded = false;
+    uint8_t code_of[256];
+    {
+        bool seen[256] = {false};
+        for (uint32_t s = 0; s < n_seq; ++s)
+            if (is_used[s])
+                for (uint64_t o = seq_off[s]; o < seq_off[s + 1]; ++o) seen[seq_bytes[o]] = true;
+        int n_alpha = 0;
+        for (int v = 0; v < 256; ++v) {
+            code_of[v] = (uint8_t)std::min(n_alpha, 7);
+            if (seen[v]) ++n_alpha;
+        }
+        const int64_t kd_match = ((int64_t)match - gap) * 4 + 2, kd_mismatch = ((int64_t)mismatch - gap) * 4 + 2;
+        coded = n_alpha <= 7 && kd_match <= 127 && kd_match >= -126 && kd_mismatch <= 127 && kd_mismatch >= -126 &&
+                !std::getenv("PWA_NO_PAIR_TABLE");
+    }
     DevBuf arena;
     {
         std::vector<uint8_t> host_arena(arena_bytes, 0);
         for (uint32_t s = 0; s < n_seq; ++s)
-            if (is_used[s] && slen(s)) std::memcpy(host_arena.data() + aoff[s], seq_bytes + seq_off[s], slen(s));
+            if (is_used[s] && slen(s)) {
+                uint8_t* dst = host_arena.data() + aoff[s];
+                const uint8_t* src = seq_bytes + seq_off[s];
+                if (coded)
+                    for (uint64_t o = 0; o < slen(s); ++o) dst[o] = code_of[src[o]];
+                else
+                    std::memcpy(dst, src, slen(s));
+            }
         HIPC(ctx, arena.alloc(arena_bytes));
         HIPC(ctx, hipMemcpy(arena.p, host_arena.data(), arena_bytes, hipMemcpyHostToDevice));
     }
@@ -1399,6 +1426,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         HIPC(ctx, hipMemcpy(d_res.p, res.data(), nc * sizeof(PairResult), hipMemcpyHostToDevice));
         mark("chunk descriptors");
         if (!pd.empty()) {
+            pl.perm = coded;
             int rc = pl.build(ctx, pd, match, mismatch, gap, geom);
             if (rc != PWA_OK) return rc;
             mark("task list build + upload");

@@ -70,13 +70,18 @@ def test_align_kats_long_pairs(ctx):
         assert sha(got["aligned_reference"]) == rec["aligned_reference_sha256"]
 
 
-def test_align_batch_matches_oracle(ctx):
+@pytest.mark.parametrize("alphabet,table", [(b"ACGT", True), (b"ACGT", False), (b"ACGTNRY", True), (b"ACDEFGHIKLMNPQRSTVWY", True)])
+def test_align_batch_matches_oracle(ctx, alphabet, table, monkeypatch):
+    """both scoring forms of the traceback fill: byte-table lookups on coded sequences (alphabets of <= 7 symbols) and
+    compare + select on raw bytes (larger alphabets, or forced)."""
+    if not table:
+        monkeypatch.setenv("PWA_NO_PAIR_TABLE", "1")
     rng = random.Random(5)
-    seqs = [bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, 400))) for _ in range(40)]
+    seqs = [bytes(rng.choice(alphabet) for _ in range(rng.randint(0, 400))) for _ in range(40)]
     pa = [rng.randrange(40) for _ in range(100)]
     pb = [rng.randrange(40) for _ in range(100)]
     for mode in ("nw", "sw"):
-        for sc in [(1, -1, -1), (2, -3, -5)]:
+        for sc in [(1, -1, -1), (2, -3, -5), (20, -15, -9), (40, -3, 2)]:   # the last two leave the byte table's range
             res = ctx.align_batch(mode, seqs, pa, pb, *sc)
             for k, r in enumerate(res):
                 want = O.align(mode, seqs[pa[k]], seqs[pb[k]], *sc)
