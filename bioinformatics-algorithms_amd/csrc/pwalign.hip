@@ -32,7 +32,15 @@ struct pwa_ctx {
     float fill_ms = 0.f, tb_ms = 0.f;
     uint64_t band_bytes = 0;
     bool score_band = false;   // pwa_ctx_set_score_band: also materialise the int32 score band in HBM
+    // Traceback / score band workspaces of pwa_align*, kept between calls (grow-only, at most kBandCacheMax each):
+    // hipMalloc of several GiB is sometimes fast (0.3 ms) and sometimes not (0.2 - 1.5 s) depending on the state of the
+    // device's memory, and a caller that aligns batch after batch should pay it once.
+    void* band_cache = nullptr;
+    size_t band_cache_bytes = 0;
+    void* sband_cache = nullptr;
+    size_t sband_cache_bytes = 0;
 };
+constexpr size_t kBandCacheMax = 24ull << 30;
 
 namespace {
 
@@ -113,6 +121,29 @@ bool tb_range_ok(uint64_t n_plus_m, int match, int mismatch, int gap) {
     const uint64_t amax = (uint64_t)std::max<int64_t>({std::llabs((long long)match), std::llabs((long long)mismatch),
                                                        std::llabs((long long)gap), 1});
     return (n_plus_m + 2) <= (1ull << 28) / amax;
+}
+
+// A workspace of `bytes` from the context's cache slot (see pwa_ctx): reused when big enough, regrown otherwise;
+// requests beyond kBandCacheMax are served by `fallback` and freed with it.
+hipError_t cached_workspace(void*& slot, size_t& slot_bytes, size_t bytes, DevBuf& fallback, void** out) {
+    if (bytes > kBandCacheMax) {
+        const hipError_t e = fallback.alloc(bytes);
+        *out = fallback.p;
+        return e;
+    }
+    if (slot_bytes < bytes) {
+        if (slot) (void)hipFree(slot);
+        slot = nullptr;
+        slot_bytes = 0;
+        const hipError_t e = hipMalloc(&slot, bytes);
+        if (e != hipSuccess) {
+            slot = nullptr;
+            return e;
+        }
+        slot_bytes = bytes;
+    }
+    *out = slot;
+    return hipSuccess;
 }
 
 int fail(pwa_ctx* c, int code, const std::string& msg) {
@@ -318,6 +349,8 @@ void pwa_ctx_destroy(pwa_ctx* c) {
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->band_cache) (void)hipFree(c->band_cache);
+    if (c->sband_cache) (void)hipFree(c->sband_cache);
     delete c;
 }
 
@@ -1380,9 +1413,12 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         k0 = k1;
     }
     DevBuf d_band, d_sband, d_ops, d_res;
+    void *p_band = nullptr, *p_sband = nullptr;
     if (!chunks.empty()) {
-        HIPC(ctx, d_band.alloc(band_cap + 32768));   // + one traceback window: the walk stages whole windows
-        if (ctx->score_band) HIPC(ctx, d_sband.alloc(band_cap * sizeof(int32_t)));
+        // + one traceback window: the walk stages whole windows
+        HIPC(ctx, cached_workspace(ctx->band_cache, ctx->band_cache_bytes, band_cap + 32768, d_band, &p_band));
+        if (ctx->score_band)
+            HIPC(ctx, cached_workspace(ctx->sband_cache, ctx->sband_cache_bytes, band_cap * sizeof(int32_t), d_sband, &p_sband));
         HIPC(ctx, d_ops.alloc(want_ops ? ops_cap_b : 16));
         HIPC(ctx, d_res.alloc(nc_cap * sizeof(PairResult)));
     }
@@ -1408,8 +1444,8 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
                 d.txt = arena.as<uint8_t>() + aoff[pair_b[k]];
                 d.n = (int32_t)n;
                 d.m = (int32_t)m;
-                d.tb = d_band.as<uint8_t>() + bo;
-                if (ctx->score_band) d.sband = d_sband.as<int32_t>() + bo;
+                d.tb = static_cast<uint8_t*>(p_band) + bo;
+                if (ctx->score_band) d.sband = static_cast<int32_t*>(p_sband) + bo;
                 d.res = d_res.as<PairResult>() + q;
                 d.ops = want_ops ? d_ops.as<uint8_t>() + oo : d_ops.as<uint8_t>();   // WALK_OVERLAP never writes ops
                 d.ops_cap = (uint32_t)std::min<uint64_t>(n + m, 0xffffffffu);
