@@ -39,6 +39,9 @@ struct pwa_ctx {
     size_t band_cache_bytes = 0;
     void* sband_cache = nullptr;
     size_t sband_cache_bytes = 0;
+    // the strip hand-off workspace of the last destroyed batch (5.2 GB for C3): the next batch takes it over
+    void* hand_cache = nullptr;
+    size_t hand_cache_bytes = 0;
 };
 constexpr size_t kBandCacheMax = 24ull << 30;
 
@@ -351,6 +354,7 @@ void pwa_ctx_destroy(pwa_ctx* c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->band_cache) (void)hipFree(c->band_cache);
     if (c->sband_cache) (void)hipFree(c->sband_cache);
+    if (c->hand_cache) (void)hipFree(c->hand_cache);
     delete c;
 }
 
@@ -817,7 +821,17 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             const uint64_t fit = std::max<uint64_t>(1, (uint64_t)(free_b * 0.6) / per_wg);
             b->grid = (uint32_t)std::min<uint64_t>(b->grid, fit);
         }
-        HIPC(ctx, b->hand.alloc((size_t)b->grid * (half + second) * sizeof(int32_t)));
+        {
+            const size_t hand_bytes = (size_t)b->grid * (half + second) * sizeof(int32_t);
+            if (ctx->hand_cache && ctx->hand_cache_bytes >= hand_bytes) {   // left behind by an earlier batch of this context
+                b->hand.p = ctx->hand_cache;
+                b->hand.bytes = ctx->hand_cache_bytes;
+                ctx->hand_cache = nullptr;
+                ctx->hand_cache_bytes = 0;
+            } else {
+                HIPC(ctx, b->hand.alloc(hand_bytes));
+            }
+        }
 
         mark("uploads + workspace");
         BatchParams& P = b->bp;
@@ -1273,6 +1287,15 @@ void pwa_batch_destroy(pwa_batch* b) {
     for (int e = 0; e < pwa_batch::kRing; ++e) {
         if (b->ev0[e]) (void)hipEventDestroy(b->ev0[e]);
         if (b->ev1[e]) (void)hipEventDestroy(b->ev1[e]);
+    }
+    // the hand-off workspace goes back to the context if it is the larger one (and not outrageous): the next batch of
+    // the same shape then skips a multi-GB hipMalloc
+    if (b->ctx && b->hand.p && b->hand.bytes > b->ctx->hand_cache_bytes && b->hand.bytes <= kBandCacheMax) {
+        if (b->ctx->hand_cache) (void)hipFree(b->ctx->hand_cache);
+        b->ctx->hand_cache = b->hand.p;
+        b->ctx->hand_cache_bytes = b->hand.bytes;
+        b->hand.p = nullptr;
+        b->hand.bytes = 0;
     }
     delete b;
 }
