@@ -32,12 +32,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.join(ROOT, "bioinformatics-algorithms_amd")
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# int32 VALU issue peak: one wave64 VALU instruction per 4 cycles per SIMD = 16 lanes/clk/SIMD.
-#   256 CU x 4 SIMD x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s  (SURVEY.md 8(d) uses the same figure).
-# Measured, not assumed: the C3 kernel retires 0.248 VALU instr/cycle/SIMD at 1, 2 and 4 waves per SIMD
-# (profiles/r01_c3_rocprof_summary.md: SQ_INSTS_VALU / GRBM_GUI_ACTIVE), and tools/valu_rate.hip shows
-# 4.1-4.6 cycles per wave64 v_max3_i32 / v_perm_b32 / v_add_u32_sdwa (and v_fma_f32) instruction.
-VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+# VALU ceiling = the architectural one of MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 VALU instruction issues over
+# 2 cycles  =>  256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-ops/s (the same rate as the guide's 157.3 TFLOP/s
+# of vector FP32 FMA).  `roofline.frac` is quoted against THIS figure, so it is <= 1 by construction.  Only the
+# adder / logic / move class of instructions reaches that rate; v_max3_i32, SDWA, v_perm_b32, compares, shifts and
+# every v_pk_* issue at half of it (tools/valu_issue.hip -> profiles/r02_valu_issue_microbench.txt), which is why a
+# DP cell of max3 + sdwa-add + perm cannot get much past 0.5 -- `roofline.issue_model` prices the actual mix.
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+# whole-workload checksums (sum of all per-pair scores of rank 0's shard at N = 1), asserted after the timed region.
+# c3: independently re-derived by the round-1 judge from 3 000 random pairs through the CPU oracle (33.739 +- 0.047 per
+# pair against 35 376 135 / 1 048 576 = 33.737) and asserted by tests/test_gpu_parity.py::test_full_size_c3_batch_properties
+EXPECTED_CHECKSUM = {"c3": 35376135}
 # VALU instructions per evaluated DP cell of each instantiation: SQ_INSTS_VALU x 64 / padded cells from the
 # rocprofv3 PMC pass (c3: 5.02, c4: 2.53; profiles/), the others counted in the gfx950 ISA of the column block
 VALU_PER_CELL = {"SC_PERM": 10.75, "SC_CMP": 12.0, "PACKED": 7.03,   # batch_nwdist_kernel<R,SCORE> / packed keys (hw4)
@@ -109,9 +114,10 @@ def _cpu_one(mode, O, kind, p, t, scoring):
     return (O.ref_align(mode, p, t, *scoring) if kind == "reference" else O.align(mode, p, t, *scoring))["score"]
 
 
-def cpu_baseline(mode, pairs, seqs, scoring, budget_s=12.0, max_pairs=1024):
+def cpu_baseline(mode, pairs, seqs, scoring, budget_s=20.0, max_pairs=1024):
     """Time the unmodified reference (oracle/_ref, kind "reference") or the C restatement (kind
-    "port") on a bounded sample of the same workload, 1 thread; then all host cores."""
+    "port") on a bounded sample of the same workload (`pairs`: a seeded random sample drawn over the WHOLE pair
+    list, so that every pattern and text can be hit), 1 thread; then all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     kind = "reference" if (O.have_ref3() if mode == "affine" else O.have_ref4() if mode == "nwdist" else O.have_ref()) else "port"
@@ -125,7 +131,7 @@ def cpu_baseline(mode, pairs, seqs, scoring, budget_s=12.0, max_pairs=1024):
             break
     dt = time.perf_counter() - t0
     out = {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": kind,
-           "sample": "first %d pairs of the workload (%.3g cells, %.1f s), %s, g++ -O2"
+           "sample": "%d pairs drawn at random (seed 481) over the whole pair list (%.3g cells, %.1f s), %s, g++ -O2"
                      % (len(scores), cells, dt, "six int matrices as hw3.cpp" if mode == "affine"
                         else "int+char matrices + traceback strings as hw4.cpp" if mode == "nwdist"
                         else "full int+char matrices as hw2.cpp")}
@@ -216,6 +222,81 @@ def build_hw4(rank, world, n_seq=1024, slen=1000):
     return "nwdist", seqs, pa, pb, (1, -1, -1), desc
 
 
+# ----------------------------------------------------------------------------- launcher
+def self_launch(args):
+    """`python bench.py --gpus N` without an external launcher: start N ranks (one process per GPU) as CHILD processes
+    and exit with their status.  Runs before anything in this process has touched HIP or torch -- no exec of a process
+    that initialised the GPU -- and stops the remaining ranks by their exact PIDs if one fails."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc, alive = 0, set(range(args.gpus))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    sys.exit(rc)
+
+
+class _RehearsalBatch:
+    """--rehearse-cpu ONLY: stands in for the HIP batch object so that the launcher, the sharding and the collective of
+    this script can be driven on a machine without a GPU (tests/test_bench_launcher.py: gloo, world 2).  Compute = the
+    CPU oracle.  The line it produces is marked invalid; the product path never comes here."""
+
+    def __init__(self, mode, seqs, pa, pb, scoring):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        self._O, self._mode, self._seqs, self._pa, self._pb, self._sc = O, mode, seqs, pa, pb, scoring
+        self.n_pairs = len(pa)
+        self._out = None
+        self._times = []
+
+    def info(self):
+        cells = sum(len(self._seqs[a]) * len(self._seqs[b]) for a, b in zip(self._pa.tolist(), self._pb.tolist()))
+        return dict(cells=cells, padded_cells=cells, n_tasks=self.n_pairs, kernel="cpu-oracle-rehearsal")
+
+    def set_out(self, tensor):
+        self._out = tensor
+
+    def run(self, stream=None):
+        t0 = time.perf_counter()
+        sc = [_cpu_one(self._mode, self._O, "port", self._seqs[a], self._seqs[b], self._sc)
+              for a, b in zip(self._pa.tolist(), self._pb.tolist())]
+        self._scores = np.asarray(sc, dtype=np.int32)
+        if self._out is not None:
+            import torch
+            self._out.copy_(torch.from_numpy(self._scores))
+        self._times.append((time.perf_counter() - t0) * 1e3)
+
+    def fetch_into(self, arr):
+        arr[:] = self._scores
+
+    def last_ms(self):
+        return self._times[-1]
+
+    def run_times(self, cap=64):
+        return self._times[-cap:]
+
+    def close(self):
+        pass
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -227,27 +308,54 @@ def main():
     ap.add_argument("--plen", type=int, default=150, help="pattern length of the g / gb workloads (150 = the C3 shape)")
     ap.add_argument("--nw", action="store_true", help="c3i: global (NW) instead of local scores")
     ap.add_argument("--small", action="store_true", help="reduced sizes (functional check only; line is marked invalid)")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="launcher / sharding / collective rehearsal without a GPU: gloo + the CPU oracle as compute "
+                         "(needs --small; the line is marked invalid)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.rehearse_cpu and not args.small:
+        raise SystemExit("--rehearse-cpu is a functional rehearsal: it needs --small")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)   # N child ranks; does not return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with matching values (or without a launcher)" % (args.gpus, world))
+    if os.environ.get("BENCH_TEST_FAIL_RANK") == str(rank) and args.rehearse_cpu:
+        raise SystemExit("rank %d: failure injected by tests/test_bench_launcher.py" % rank)
     dist = None
     torch = None
     # BENCH_FORCE_DIST=1 takes the distributed code path (RCCL init, explicit stream, all-gather) even with
     # one rank: rehearsal on a 1-GPU box under `python -m torch.distributed.run --nproc-per-node 1 ...`
     use_dist = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))
+    cpu = args.rehearse_cpu
+    dist_info = None
     if use_dist:
         import torch   # noqa: F811
         import torch.distributed as dist   # noqa: F811
         os.environ["NCCL_DEBUG"] = os.environ.get("BENCH_NCCL_DEBUG", "WARN")   # keep RCCL's banner off stdout: ONE JSON line
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if cpu:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+        # which device every rank drives: gathered once, reported in the line (proof that N ranks on N devices took part)
+        dev = torch.tensor([-1 if cpu else torch.cuda.current_device()], dtype=torch.int32, device="cpu" if cpu else "cuda")
+        devs = [torch.empty_like(dev) for _ in range(dist.get_world_size())]
+        dist.all_gather(devs, dev)
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "launcher": "bench.py --gpus N (child processes)" if os.environ.get("BENCH_SELF_LAUNCHED") else "external (torch.distributed.run)",
+                     "device_of_rank": [int(d.item()) for d in devs]}
 
-    pkg = load_pkg()
-    ctx = pkg.Context(local_rank)
+    pkg = ctx = None
+    if not cpu:
+        pkg = load_pkg()
+        ctx = pkg.Context(local_rank)
 
     if args.workload in ("g", "gb"):
         return bench_global_batch(args, pkg, ctx)
@@ -256,6 +364,8 @@ def main():
 
     if args.workload == "c3":
         kw = dict(n_patterns=256, n_texts=16, tlen=2000) if args.small else {}
+        if cpu:
+            kw = dict(n_patterns=24, n_texts=4, tlen=300)
         mode, seqs, pa, pb, scoring, desc = build_c3(rank, **kw)
         scaling = "weak"
     elif args.workload == "c3i":
@@ -271,10 +381,14 @@ def main():
         scaling = "strong"
     else:
         kw = dict(n_seq=128) if args.small else {}
+        if cpu:
+            kw = dict(n_seq=12, slen=120)
         mode, seqs, pa, pb, scoring, desc = build_c4(rank, world, **kw)
         scaling = "strong"
 
     def make_batch():
+        if cpu:
+            return _RehearsalBatch(mode, seqs, pa, pb, scoring)
         if mode == "affine":
             return ctx.batch_affine(seqs, pa, pb, *scoring)
         if mode == "nwdist":
@@ -284,38 +398,50 @@ def main():
     batch = make_batch()
     info = batch.info()
     n_pairs = len(pa)
+    scores = np.zeros(max(n_pairs, 1), dtype=np.int32)[:n_pairs]   # host copy of this rank's per-pair scores, refreshed every step
 
     stream = None
     mine = None
     shard = None
     state = {"gathered": None}
     if use_dist:
-        from bioinformatics_algorithms_amd import shard
-        # a real (non-default) torch stream: the kernels are enqueued on it through the C ABI and the
-        # collective, issued under the same current stream, is ordered behind them
-        tstream = torch.cuda.Stream()
-        torch.cuda.set_stream(tstream)
-        stream = tstream.cuda_stream
-        assert stream != 0
-        mine = torch.empty(max(n_pairs, 1), dtype=torch.int32, device="cuda")[:n_pairs]
-        batch.set_d_scores(mine.data_ptr())   # kernels write the scores straight into the tensor the collective sends
+        if cpu:
+            load_pkg_shard = importlib.util.spec_from_file_location("pwa_shard", os.path.join(PKG_DIR, "shard.py"))
+            shard = importlib.util.module_from_spec(load_pkg_shard)
+            load_pkg_shard.loader.exec_module(shard)
+            mine = torch.empty(max(n_pairs, 1), dtype=torch.int32)[:n_pairs]
+            batch.set_out(mine)
+        else:
+            from bioinformatics_algorithms_amd import shard
+            # a real (non-default) torch stream: the kernels are enqueued on it through the C ABI and the
+            # collective, issued under the same current stream, is ordered behind them
+            tstream = torch.cuda.Stream()
+            torch.cuda.set_stream(tstream)
+            stream = tstream.cuda_stream
+            assert stream != 0
+            mine = torch.empty(max(n_pairs, 1), dtype=torch.int32, device="cuda")[:n_pairs]
+            batch.set_d_scores(mine.data_ptr())   # kernels write the scores straight into the tensor the collective sends
     n_total = desc.get("pairs_total", n_pairs * world)
     per = desc.get("_per", n_pairs)
 
     def step():
+        # one pass of the hot path: kernels, the collective (N > 1), and the per-pair results back in host memory --
+        # "kernel + transfer of per-pair results included"
         batch.run(stream)
         if use_dist:   # RCCL all-gather of the per-pair int32 scores over xGMI (the path's only collective)
             if args.workload in ("c4", "hw3", "hw4"):
                 state["gathered"] = shard.all_gather_scores(mine, n_total, per, dist)
             else:       # weak scaling: every rank contributes n_pairs scores of its own texts
                 if state["gathered"] is None:
-                    state["gathered"] = torch.empty(world * n_pairs, dtype=torch.int32, device="cuda")
+                    state["gathered"] = torch.empty(world * n_pairs, dtype=torch.int32, device=mine.device)
                 dist.all_gather_into_tensor(state["gathered"], mine)
+        batch.fetch_into(scores)   # waits for this step's kernels (their event), then D2H of this rank's scores
 
     def sync():
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not cpu:
+                torch.cuda.synchronize()
         else:
             batch.last_ms()   # event-synchronises the library's stream
 
@@ -332,16 +458,23 @@ def main():
     kernel_ms = batch.run_times(min(args.steps, 64))   # HIP events on the launch stream, per step
     cells = info["cells"]
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tdev = "cpu" if cpu else "cuda"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([float(cells)], dtype=torch.float64, device="cuda")
+        c = torch.tensor([float(cells)], dtype=torch.float64, device=tdev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         cells_total = float(c.item())
+        # every rank holds the same gathered vector: compare a digest of it across ranks (sum and a position-weighted sum)
+        g = state["gathered"].to(torch.int64)
+        dig = torch.stack([g.sum(), (g * (torch.arange(g.numel(), device=g.device) % 1009 + 1)).sum()]).to(tdev)
+        digs = [torch.empty_like(dig) for _ in range(world)]
+        dist.all_gather(digs, dig)
+        gathered_same = all(bool((d == digs[0]).all().item()) for d in digs)
+        gathered_sum = int(digs[0][0].item())
     else:
         cells_total = float(cells)
 
-    scores = batch.fetch(numpy_out=True)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -363,13 +496,17 @@ def main():
         "kernel": kern,
         "achieved": (padded / (k_ms * 1e-3)) * ops / 1e12 if ops else None,
         "peak": VALU_PEAK_TOPS,
+        "peak_source": "MI355X_MICROARCH.md: 4 SIMD-32 per CU, wave64 VALU over 2 cycles: 256 x 4 x 32 lanes x 2.4 GHz",
         "unit": "Tiop/s",
         "frac": ((padded / (k_ms * 1e-3)) * ops / 1e12) / VALU_PEAK_TOPS if ops else None,
         "valu_ops_per_cell": ops,
         "issue_model": ({"cycles_per_cell_model": ISSUE_CYCLES_PER_CELL[key],
                          "cycles_per_cell_measured": (k_ms * 1e-3) * 2.4e9 * 1024 / (padded / 64.0),
-                         "frac": ISSUE_CYCLES_PER_CELL[key] / ((k_ms * 1e-3) * 2.4e9 * 1024 / (padded / 64.0)),
-                         "source": "profiles/r01_valu_class_microbench.txt (per-instruction issue costs, 2.4 GHz nominal)"}
+                         "ratio": ISSUE_CYCLES_PER_CELL[key] / ((k_ms * 1e-3) * 2.4e9 * 1024 / (padded / 64.0)),
+                         "note": "model = sum over the cell's instructions of their measured per-class issue cost (full-rate "
+                                 "class ~2.7-3.2 cycles, half-rate class ~4.45; >= 2 waves per SIMD) at the NOMINAL 2.4 GHz; "
+                                 "a ratio near 1 says the loop issues at the per-class rates, it is not a roofline fraction",
+                         "source": "profiles/r01_valu_class_microbench.txt, profiles/r02_valu_issue_microbench.txt"}
                         if key in ISSUE_CYCLES_PER_CELL else None),
         "kernel_ms": k_ms,
         "kernel_gcups": kernel_gcups,
@@ -399,36 +536,53 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "int32", "data": "synthetic",
         "config": {k: v for k, v in desc.items() if not k.startswith("_")},
+        "step_includes": "kernels" + (" + all-gather of the per-pair scores" if use_dist else "") + " + D2H of this rank's per-pair scores",
         "roofline": roofline,
     }
+    if dist_info is not None:
+        line["dist"] = dict(dist_info, gathered_identical_on_all_ranks=gathered_same, gathered_score_sum=gathered_sum)
+        if not gathered_same:
+            line["invalid"] = "the gathered score vectors differ between ranks"
     if args.small:
         line["invalid"] = "reduced sizes (--small): functional check only"
+    if cpu:
+        line["invalid"] = "CPU rehearsal of the launcher / sharding / collective (gloo + oracle): not a measurement"
 
-    if world == 1 and not args.no_cpu_baseline:
-        pairs = list(zip(pa[:4096].tolist(), pb[:4096].tolist()))
+    line["checksum"] = int(np.asarray(scores, dtype=np.int64).sum())
+    want_sum = EXPECTED_CHECKSUM.get(args.workload) if (mode == "sw" and not args.small and not cpu) else None
+    if want_sum is not None:
+        line["checksum_expected"] = want_sum
+        if line["checksum"] != want_sum:
+            line["invalid"] = "checksum of rank 0's scores is %d, expected %d" % (line["checksum"], want_sum)
+
+    if world == 1 and not args.no_cpu_baseline and not cpu:
+        # verification + CPU baseline on the SAME sample: >= 1024 pairs drawn over the whole pair list (all patterns, all texts)
+        rs = np.random.RandomState(481)
+        pick = np.sort(rs.choice(n_pairs, size=min(n_pairs, 1024), replace=False))
+        pairs = list(zip(pa[pick].tolist(), pb[pick].tolist()))
         base, ref_scores = cpu_baseline(mode, pairs, seqs, scoring)
         line["cpu_baseline"] = base
-        ok = all(int(scores[k]) == ref_scores[k] for k in range(len(ref_scores)))
-        line["verified_vs_cpu"] = {"pairs": len(ref_scores), "bit_exact": bool(ok)}
+        ok = all(int(scores[pick[k]]) == ref_scores[k] for k in range(len(ref_scores)))
+        line["verified_vs_cpu"] = {"pairs": len(ref_scores), "distinct_patterns": int(len(set(pa[pick[:len(ref_scores)]].tolist()))),
+                                   "distinct_texts": int(len(set(pb[pick[:len(ref_scores)]].tolist()))), "bit_exact": bool(ok)}
         if not ok:
             line["invalid"] = "GPU scores differ from the CPU baseline"
-    if world == 1:
+    if world == 1 and not cpu:
         # whole host call on HOST buffers (never `value`): sequence upload over PCIe, host-side wave-task
         # scheduling, kernel, score download
         t1 = time.perf_counter()
-        again = None
-        if again is None:
-            b2 = make_batch()
-            b2.run()
-            again = b2.fetch(numpy_out=True)
-            b2.close()
+        b2 = make_batch()
+        b2.run()
+        b2.fetch(numpy_out=True)
+        b2.close()
         dt = time.perf_counter() - t1
         line["host_call_inclusive"] = {"gcups": cells / dt / 1e9, "ms": dt * 1e3,
                                        "what": "pwa_batch_create (PCIe upload + host scheduling) + run + fetch"}
-    line["checksum"] = int(np.asarray(scores, dtype=np.int64).sum())
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if "invalid" in line and not (args.small or cpu):
+        sys.exit(3)   # a full-size line that failed its own checks must not look like a result
 
 
 def bench_global_batch(args, pkg, ctx):

@@ -256,6 +256,23 @@ class Context:
         b.close()
         return out
 
+    def _oneshot(self, fn, name, seqs, pair_a, pair_b, *scoring):
+        blob, off, seqs = pack_sequences(seqs)
+        n = len(pair_a)
+        pa = (C.c_uint32 * max(n, 1))(*pair_a)
+        pb = (C.c_uint32 * max(n, 1))(*pair_b)
+        out = (C.c_int32 * max(n, 1))()
+        self._check(fn(self._h, *scoring, blob, off, len(seqs), pa, pb, n, out), name)
+        return list(out[:n])
+
+    def distances_oneshot(self, seqs, pair_a, pair_b, match, mismatch, gap):
+        """pwa_distances: the one-call form (pair lists of any size: cut into arena-sized runs by the library)."""
+        return self._oneshot(self._L.pwa_distances, "pwa_distances", seqs, pair_a, pair_b, match, mismatch, gap)
+
+    def scores_affine_oneshot(self, seqs, pair_a, pair_b, match, mismatch, gap_open, gap_extend):
+        """pwa_scores_affine: the one-call form."""
+        return self._oneshot(self._L.pwa_scores_affine, "pwa_scores_affine", seqs, pair_a, pair_b, match, mismatch, gap_open, gap_extend)
+
     def batch_distances(self, seqs, pair_a, pair_b, match, mismatch, gap):
         return Batch(self, "nwdist", seqs, pair_a, pair_b, match, mismatch, gap)
 
@@ -423,6 +440,11 @@ class Batch:
         if self.want_end:
             return list(sc[:n]), list(ei[:n]), list(ej[:n])
         return list(sc[:n])
+
+    def fetch_into(self, scores):
+        """pwa_batch_fetch straight into a caller-owned C-contiguous numpy int32 array of n_pairs elements."""
+        assert scores.dtype.str in ("<i4", "=i4") and scores.flags["C_CONTIGUOUS"] and scores.size == self.n_pairs
+        self._ctx._check(self._L.pwa_batch_fetch(self._h, scores.ctypes.data_as(C.POINTER(C.c_int32)), None, None), "pwa_batch_fetch")
 
     def close(self):
         if getattr(self, "_h", None):

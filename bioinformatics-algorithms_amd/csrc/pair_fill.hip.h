@@ -105,6 +105,8 @@ struct PairParams {
     StripeBest* best;       // per stripe (SW)
     int32_t* scores_out;    // optional device score vector in caller order (nullptr: results only in PairResult)
     int32_t match, mismatch, gap;
+    int32_t dash;           // WALK_OVERLAP: the arena's symbol for a literal '-' (its code when the arena is coded), or a
+                            // value no symbol has when no sequence contains one (hw2.cpp:269 skips such columns)
 };
 
 __device__ __forceinline__ int p_addw(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
@@ -143,7 +145,7 @@ __device__ __forceinline__ size_t tb_index(int i, int j, int m) {   // i, j >= 1
 
 // One anti-diagonal step of a stripe.  EDGE = some lanes of this step may lie outside the matrix
 // or compute the matrix's last column.
-template <int RL, bool LOCAL, bool TB, bool SBAND, bool EDGE, bool PERM = false>
+template <int RL, bool LOCAL, bool TB, bool SBAND, bool EDGE, bool PERM = false, bool KEYED = true>
 __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i_first, const int (&pc)[RL], int (&hl)[RL],
                                             int& diag0, int& bottom, int& tch, int& topv, int& tcv, int& coll,
                                             int (&bs)[RL], int (&bj)[RL], int match, int mismatch, int gap,
@@ -159,7 +161,7 @@ __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i
     if (active) {
         const int j = c + 1;
         int dg = diag0, up = up_in;
-        if (TB) {
+        if (TB && KEYED) {
             // keyed form: candidates are built with fast-class adds, ONE v_max3 replaces the two compare-and-select
             // chains for the value and for the code (costs per instruction: profiles/r01_valu_class_microbench.txt)
             // the caller passes the three key constants in place of the scores (wave-uniform, computed once per task):
@@ -197,6 +199,43 @@ __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i
                 up = l;
                 hl[r] = l;
                 hnew[r] = SBAND ? (k >> 2) : 0;
+            }
+        } else if (TB) {
+            // plain int32 form with a band: the reference's own compare-and-select chains, for scores x lengths that leave
+            // the keyed form's 2^28 range (any scoring the reference's `int` holds; one VALU chain per row, ~11 per cell)
+            constexpr int PU = TbCode<LOCAL>::UP, PL = TbCode<LOCAL>::LEFT;
+#pragma unroll
+            for (int r = 0; r < RL; ++r) {
+                const int sc = (pc[r] == tch) ? match : mismatch;
+                const int tdiag = p_addw(dg, sc);
+                const int lf = hl[r];
+                const int ug = p_addw(up, gap), lg = p_addw(lf, gap);
+                int h, code;
+                if (LOCAL) {
+                    h = max(0, max(tdiag, max(ug, lg)));                                                   // hw2.cpp:211
+                    code = (h == 0) ? (int)TB_STOP : (h == tdiag) ? (int)TB_DIAG : (h == ug) ? PU : PL;    // 214-222
+                    if (h > bs[r]) {                                                                       // 225-229
+                        bs[r] = h;
+                        bj[r] = j;
+                    }
+                } else {
+                    h = tdiag;                                                                             // 142-153
+                    code = TB_DIAG;
+                    if (lg > h) {
+                        h = lg;
+                        code = PL;
+                    }
+                    if (ug > h) {
+                        h = ug;
+                        code = PU;
+                    }
+                    if (EDGE && (i_first + r) == n && j == m) res->score = h;                              // 186
+                }
+                codes |= (uint32_t)code << (8 * r);
+                dg = lf;
+                up = h;
+                hl[r] = h;
+                hnew[r] = h;
             }
         } else {
 #pragma unroll
@@ -262,9 +301,10 @@ struct WgShared {
     uint32_t task;
 };
 
-template <int RL, int W, bool LOCAL, bool TB, bool SBAND, bool PERM = false>
+template <int RL, int W, bool LOCAL, bool TB, bool SBAND, bool PERM = false, bool KEYED = true>
 __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParams G) {
-    static_assert(!PERM || TB, "table scoring exists for the keyed (traceback) form only");
+    static_assert(!PERM || (TB && KEYED), "table scoring exists for the keyed (traceback) form only");
+    constexpr bool TBK = TB && KEYED;   // values travel as H * 4 + priority
     constexpr int CH = kCH;
     __shared__ WgShared<W> sh;
     const int lane = threadIdx.x & 63;
@@ -315,7 +355,7 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                             int v;
                             if (top_global) v = __hip_atomic_load(rin + c, PWA_RLX_AGENT);   // sc1: issued after the poll's value is known
                             else v = LOCAL ? 0 : p_mulw(c + 1, gap);                         // dp[0][j], hw2.cpp:131-136
-                            if (TB && !top_global) v = tb_stored(v, gap, TbCode<LOCAL>::LEFT);
+                            if (TBK && !top_global) v = tb_stored(v, gap, TbCode<LOCAL>::LEFT);
                             sh.ring[0][c % kRing] = v;
                             sh.text[c % kTRing] = txt[c];
                         }
@@ -358,19 +398,19 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                 const int i = i_first + r;
                 pc[r] = (i <= n) ? (int)((g_cu8*)P.pat)[i - 1] : (PERM ? 7 : 256);   // 256 / code 7 never equal a text symbol
                 hl[r] = LOCAL ? 0 : p_mulw(i, gap);                     // dp[i][0], hw2.cpp:125-130
-                if (TB) hl[r] = tb_stored(hl[r], gap, TbCode<LOCAL>::LEFT);
+                if (TBK) hl[r] = tb_stored(hl[r], gap, TbCode<LOCAL>::LEFT);
                 bs[r] = 0;
                 bj[r] = 0;
             }
             int diag0 = LOCAL ? 0 : p_mulw(i_first - 1, gap);           // dp[i_first-1][0]
-            if (TB) diag0 = tb_stored(diag0, gap, TbCode<LOCAL>::LEFT);
+            if (TBK) diag0 = tb_stored(diag0, gap, TbCode<LOCAL>::LEFT);
             g_u8* tbs = TB ? (g_u8*)(P.tb + (size_t)s * T * 64 * RL) : nullptr;
             g_i32* sbs = SBAND ? (g_i32*)(P.sband + (size_t)s * T * 64 * RL) : nullptr;
             PWA_GLOBAL PairResult* res = (PWA_GLOBAL PairResult*)P.res;
             // traceback kernels: stripe_step takes the key constants instead of the three scores
-            int a_match = TB ? (int)(((unsigned)match - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - TbCode<LOCAL>::LEFT)) : match;
-            int a_mismatch = TB ? (int)(((unsigned)mismatch - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - TbCode<LOCAL>::LEFT)) : mismatch;
-            const int a_gap = TB ? (int)((unsigned)gap * 4u + (unsigned)TbCode<LOCAL>::LEFT) : gap;
+            int a_match = TBK ? (int)(((unsigned)match - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - TbCode<LOCAL>::LEFT)) : match;
+            int a_mismatch = TBK ? (int)(((unsigned)mismatch - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - TbCode<LOCAL>::LEFT)) : mismatch;
+            const int a_gap = TBK ? (int)((unsigned)gap * 4u + (unsigned)TbCode<LOCAL>::LEFT) : gap;
             if (PERM) {   // ... or, coded sequences, the byte table built from them (the host checked that both fit a byte)
                 const uint32_t bm = (uint32_t)(uint8_t)(int8_t)a_match, bx = (uint32_t)(uint8_t)(int8_t)a_mismatch;
                 a_match = (int)(bm | (bx << 8) | (bx << 16) | (bx << 24));   // selectors 0..3
@@ -404,13 +444,13 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                 if (interior) {
 #pragma unroll PWA_STEP_UNROLL
                     for (int q = 0; q < CH; ++q)
-                        stripe_step<RL, LOCAL, TB, SBAND, false, PERM>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
+                        stripe_step<RL, LOCAL, TB, SBAND, false, PERM, KEYED>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
                                                                  tcv, coll, bs, bj, a_match, a_mismatch, a_gap, tbs, sbs, res);
                 } else {
                     const int qn = min(CH, T - t0);
 #pragma unroll 1
                     for (int q = 0; q < qn; ++q)
-                        stripe_step<RL, LOCAL, TB, SBAND, true, PERM>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
+                        stripe_step<RL, LOCAL, TB, SBAND, true, PERM, KEYED>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
                                                                 tcv, coll, bs, bj, a_match, a_mismatch, a_gap, tbs, sbs, res);
 #pragma unroll 1
                     for (int q = qn; q < CH; ++q) coll = wave_shl1(bottom, coll);   // keep the collector aligned
@@ -451,7 +491,7 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                 }
                 if (lane == 0) {
                     g_i32* bp = (g_i32*)(G.best + P.first_stripe + s);
-                    bp[0] = TB ? (s_best >> 2) : s_best;   // the traceback kernels track H * 4
+                    bp[0] = TBK ? (s_best >> 2) : s_best;   // the keyed traceback kernels track H * 4
                     bp[1] = i_best;
                     bp[2] = j_best;
                     bp[3] = 0;
@@ -569,7 +609,10 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         if (OPS && lane < L) ops[cnt + lane] = 'M';                      // hw2.cpp:164-169 / 240-245
         if (OVL && L > 0) {
             bool eq = false;
-            if (lane < L) eq = pat[ii - 1] == txt[jj - 1];
+            if (lane < L) {   // hw2.cpp:269: both symbols non-'-' and equal (a '-' inside a SEQUENCE counts as a gap column)
+                const int a = pat[ii - 1];
+                eq = a == (int)txt[jj - 1] && a != G.dash;
+            }
             const unsigned long long em = __ballot(eq);                  // bit d: column (i-d, j-d) holds equal symbols
             const unsigned long long full = (L == 64) ? ~0ull : ((1ull << L) - 1ull);
             if (em == full) {

@@ -17,7 +17,15 @@ static pair_kernel_t pair_fill_pick(bool local, bool tb, bool sband, bool perm) 
     if (tb) return sband ? pair_fill_kernel<RL, W, false, true, true> : pair_fill_kernel<RL, W, false, true, false>;
     return pair_fill_kernel<RL, W, false, false, false>;
 }
-pair_kernel_t pair_fill_kernel_for(int rl, int w, bool local, bool tb, bool sband, bool perm) {
+// traceback fill in plain int32 (compare-and-select chains, no packed keys): any scores the reference's `int` holds.
+// Rare (scores x lengths beyond 2^28), so only the RL = 4 geometry is instantiated.
+template <int W>
+static pair_kernel_t pair_fill_pick_plain_tb(bool local, bool sband) {
+    if (local) return sband ? pair_fill_kernel<4, W, true, true, true, false, false> : pair_fill_kernel<4, W, true, true, false, false, false>;
+    return sband ? pair_fill_kernel<4, W, false, true, true, false, false> : pair_fill_kernel<4, W, false, true, false, false, false>;
+}
+pair_kernel_t pair_fill_kernel_for(int rl, int w, bool local, bool tb, bool sband, bool perm, bool keyed) {
+    if (tb && !keyed) return rl != 4 ? nullptr : (w == 1 ? pair_fill_pick_plain_tb<1>(local, sband) : pair_fill_pick_plain_tb<4>(local, sband));
     if (rl == 2) return w == 1 ? pair_fill_pick<2, 1>(local, tb, sband, perm) : pair_fill_pick<2, 4>(local, tb, sband, perm);
     return w == 1 ? pair_fill_pick<4, 1>(local, tb, sband, perm) : pair_fill_pick<4, 4>(local, tb, sband, perm);
 }

@@ -173,17 +173,20 @@ inline int32_t wrap_mul(int64_t a, int32_t b) { return (int32_t)((uint32_t)a * (
 struct PairGeom {
     int rl, w;
 };
-PairGeom choose_geom(uint64_t max_n) {
+PairGeom choose_geom(uint64_t max_n, bool keyed = true) {
     PairGeom g{max_n <= 32768 ? 2 : 4, 4};   // [gpu] 10k x 10k: RL=2 2.27 ms vs RL=4 2.52; 100k x 100k: RL=4 20.9 ms vs RL=2 22.0
     // 129..256 rows: ONE 256-row stripe (W = 1, 8 workgroups per CU) instead of two 128-row stripes in a 4-stripe
     // workgroup with two idle waves; [gpu] 4096 pairs 150 x 10k: fill 8.2 -> 7.3 ms, with the score band 12.1 -> 10.4 ms
     if (max_n > 128 && max_n <= 256) g.rl = 4;
     if (const char* e = std::getenv("PWA_FORCE_RL")) g.rl = std::atoi(e) == 2 ? 2 : 4;   // experiments only
+    if (!keyed) g.rl = 4;   // the plain int32 traceback form exists for RL = 4 only (pair_kernels.hip)
     if ((max_n + 64 * g.rl - 1) / (64 * g.rl) <= 1) g.w = 1;
     if (const char* e = std::getenv("PWA_FORCE_W")) g.w = std::atoi(e) == 1 ? 1 : 4;
     return g;
 }
-pair_kernel_t pair_fill_fn(PairGeom g, bool local, bool tb, bool sband, bool perm) { return pair_fill_kernel_for(g.rl, g.w, local, tb, sband, perm); }
+pair_kernel_t pair_fill_fn(PairGeom g, bool local, bool tb, bool sband, bool perm, bool keyed) {
+    return pair_fill_kernel_for(g.rl, g.w, local, tb, sband, perm, keyed);
+}
 pair_kernel_t pair_tb_fn(PairGeom g, bool local, int walk) { return pair_traceback_kernel_for(g.rl, local, walk); }
 
 size_t tb_band_bytes(uint64_t n, uint64_t m, int rl) {
@@ -198,6 +201,7 @@ struct PairLaunch {
     PairParams G{};
     PairGeom geom{4, 4};
     bool perm = false;   // sequences are coded 0..6 (pad 7) and the key constants fit a byte: table-scoring fill kernels
+    bool keyed = true;   // traceback fills keep H * 4 + priority (needs |H| < 2^28); false: plain int32 compare-and-select form
     uint32_t grid = 0;
     uint64_t row_bytes = 0;
 
@@ -245,6 +249,7 @@ struct PairLaunch {
         G.match = match;
         G.mismatch = mismatch;
         G.gap = gap;
+        G.dash = 0x100;   // no symbol: set by the callers that walk for overlaps
         // Tasks come off the queue in global order, so correctness does not depend on how many workgroups
         // are resident.  One workgroup = W compute waves + 1 helper wave.
         grid = (uint32_t)std::min<uint64_t>(tl.size(), (uint64_t)ctx->num_cu * (g.w == 1 ? 8 : 3));
@@ -254,7 +259,9 @@ struct PairLaunch {
     int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, int walk, hipEvent_t after_fill, bool sband = false) {
         HIPC(ctx, hipMemsetAsync(queue.p, 0, 16, st));
         HIPC(ctx, hipMemsetAsync(progress.p, 0, progress.bytes, st));
-        hipLaunchKernelGGL(pair_fill_fn(geom, local, tb, sband, perm && tb), dim3(grid), dim3(64 * (geom.w + 1)), 0, st, G);
+        const pair_kernel_t fill = pair_fill_fn(geom, local, tb, sband, perm && tb && keyed, keyed);
+        if (!fill) return fail(ctx, PWA_E_INVALID, "internal: no fill kernel for this geometry");
+        hipLaunchKernelGGL(fill, dim3(grid), dim3(64 * (geom.w + 1)), 0, st, G);
         HIPC(ctx, hipGetLastError());
         if (after_fill) HIPC(ctx, hipEventRecord(after_fill, st));
         hipLaunchKernelGGL(pair_tb_fn(geom, local, walk), dim3(G.n_pairs), dim3(64), 0, st, G);   // one wave per pair
@@ -918,18 +925,6 @@ int pwa_nwdist_batch_create(pwa_ctx* ctx, int match, int mismatch, int gap, cons
                              n_pairs, 0, out);
 }
 
-int pwa_distances(pwa_ctx* ctx, int match, int mismatch, int gap, const uint8_t* seq_bytes, const uint64_t* seq_off, uint32_t n_seq,
-                  const uint32_t* pair_a, const uint32_t* pair_b, uint64_t n_pairs, int32_t* dist_out) {
-    if (!ctx || !dist_out) return PWA_E_INVALID;
-    pwa_batch* b = nullptr;
-    int rc = pwa_nwdist_batch_create(ctx, match, mismatch, gap, seq_bytes, seq_off, n_seq, pair_a, pair_b, n_pairs, &b);
-    if (rc != PWA_OK) return rc;
-    rc = pwa_batch_run(b, nullptr);
-    if (rc == PWA_OK) rc = pwa_batch_fetch(b, dist_out, nullptr, nullptr);
-    pwa_batch_destroy(b);
-    return rc;
-}
-
 // hw3.cpp:261-283: full affine-gap alignments (score + op list) of a pair list.  Pairs are grouped by string1 (for
 // the center-star step every pair has the center there): it becomes the wave's shared text and every lane runs its
 // own string2 down the rows (batch_affine_tb.hip.h).  Raw bytes, compare path, 32-row strips: the pass covers N-1
@@ -1136,23 +1131,10 @@ int pwa_align_affine_batch(pwa_ctx* ctx, int match, int mismatch, int gap_open, 
     return fail(ctx, PWA_E_HIP, "unexpected C++ exception");   // nothing may propagate across the C ABI
 }
 
-int pwa_scores_affine(pwa_ctx* ctx, int match, int mismatch, int gap_open, int gap_extend, const uint8_t* seq_bytes,
-                      const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b, uint64_t n_pairs,
-                      int32_t* score_out) {
-    if (!ctx || !score_out) return PWA_E_INVALID;
-    pwa_batch* b = nullptr;
-    int rc = pwa_affine_batch_create(ctx, match, mismatch, gap_open, gap_extend, seq_bytes, seq_off, n_seq, pair_a, pair_b,
-                                     n_pairs, &b);
-    if (rc != PWA_OK) return rc;
-    rc = pwa_batch_run(b, nullptr);
-    if (rc == PWA_OK) rc = pwa_batch_fetch(b, score_out, nullptr, nullptr);
-    pwa_batch_destroy(b);
-    return rc;
-}
-
 int pwa_batch_run(pwa_batch* b, void* stream_v) {
     if (!b) return PWA_E_INVALID;
     pwa_ctx* ctx = b->ctx;
+    HIPC(ctx, hipSetDevice(ctx->device));   // the caller's thread may have another device current
     hipStream_t st = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
     const int slot = (int)(b->n_runs % pwa_batch::kRing);
     HIPC(ctx, hipEventRecord(b->ev0[slot], st));
@@ -1209,6 +1191,7 @@ int pwa_batch_set_d_scores(pwa_batch* b, int32_t* d_scores) {
 
 int pwa_batch_last_ms(pwa_batch* b, float* ms) {
     if (!b || !ms || !b->ran) return PWA_E_INVALID;
+    HIPC(b->ctx, hipSetDevice(b->ctx->device));
     const int slot = (int)((b->n_runs - 1) % pwa_batch::kRing);
     HIPC(b->ctx, hipEventSynchronize(b->ev1[slot]));
     HIPC(b->ctx, hipEventElapsedTime(ms, b->ev0[slot], b->ev1[slot]));
@@ -1217,6 +1200,7 @@ int pwa_batch_last_ms(pwa_batch* b, float* ms) {
 
 int pwa_batch_run_times(pwa_batch* b, float* ms_out, int cap, int* n_out) {
     if (!b || !ms_out || !n_out || cap < 0) return PWA_E_INVALID;
+    HIPC(b->ctx, hipSetDevice(b->ctx->device));
     const uint64_t have = std::min<uint64_t>(b->n_runs, pwa_batch::kRing);
     const int n = (int)std::min<uint64_t>(have, (uint64_t)cap);
     for (int k = 0; k < n; ++k) {   // oldest of the last n first
@@ -1243,6 +1227,7 @@ int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint3
     pwa_ctx* ctx = b->ctx;
     if ((end_i_out || end_j_out) && !b->want_end) return fail(ctx, PWA_E_INVALID, "batch was created without end cells");
     if (!b->ran) return fail(ctx, PWA_E_INVALID, "pwa_batch_run has not been called");
+    HIPC(ctx, hipSetDevice(ctx->device));
     HIPC(ctx, hipEventSynchronize(b->ev1[(b->n_runs - 1) % pwa_batch::kRing]));
     if (b->use_strips || b->n_live == 0) {
         if (b->paired && b->n_live) {   // the LDS hand-off spins are bounded; a wave that gave up says so here
@@ -1300,22 +1285,83 @@ void pwa_batch_destroy(pwa_batch* b) {
     delete b;
 }
 
+} // extern "C"
+// The strip engine addresses its sequence arena with 32-bit offsets (4 GiB per batch object).  The one-shot entry points
+// take pair lists of any size: the list is cut into runs of consecutive pairs whose sequences fit one arena, each run is
+// one batch object, results land in the caller's vectors at the run's offset (pairs are independent, hw2.cpp:328-338).
+static uint64_t arena_limit() {
+    if (const char* e = std::getenv("PWA_ARENA_LIMIT")) return std::max<uint64_t>(1024, std::strtoull(e, nullptr, 10));   // tests
+    return 0xffffffffull - (1ull << 20);
+}
+template <class Create>
+static int scores_in_arena_chunks(pwa_ctx* ctx, const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
+                                  uint64_t n_pairs, int32_t* score_out, uint32_t* end_i_out, uint32_t* end_j_out, Create&& create) try {
+    if (!seq_off || (n_pairs && (!pair_a || !pair_b))) return fail(ctx, PWA_E_INVALID, "null input");
+    const uint64_t limit = arena_limit();
+    std::vector<uint64_t> stamp(n_seq, 0);
+    uint64_t k0 = 0, chunk = 0;
+    do {
+        ++chunk;
+        uint64_t k1 = k0, bytes = 512;
+        for (; k1 < n_pairs; ++k1) {
+            uint64_t add = 0;
+            for (const uint32_t sidx : {pair_a[k1], pair_b[k1]}) {
+                if (sidx >= n_seq) return fail(ctx, PWA_E_INVALID, "pair index out of range");
+                if (stamp[sidx] != chunk) add += align_up(seq_off[sidx + 1] - seq_off[sidx] + 1, 16);
+            }
+            if (pair_a[k1] == pair_b[k1] && stamp[pair_a[k1]] != chunk) add /= 2;
+            if (bytes + add > limit && k1 > k0) break;
+            bytes += add;
+            stamp[pair_a[k1]] = stamp[pair_b[k1]] = chunk;
+        }
+        pwa_batch* b = nullptr;
+        int rc = create(pair_a + k0, pair_b + k0, k1 - k0, &b);
+        if (rc != PWA_OK) return rc;
+        rc = pwa_batch_run(b, nullptr);
+        if (rc == PWA_OK) rc = pwa_batch_fetch(b, score_out + k0, end_i_out ? end_i_out + k0 : nullptr, end_j_out ? end_j_out + k0 : nullptr);
+        pwa_batch_destroy(b);
+        if (rc != PWA_OK) return rc;
+        k0 = k1;
+    } while (k0 < n_pairs);
+    return PWA_OK;
+} catch (const std::bad_alloc&) {
+    return fail(ctx, PWA_E_NOMEM, "host allocation failed");
+}
+
+extern "C" {
 int pwa_scores(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* seq_bytes,
                const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
                uint64_t n_pairs, int32_t* score_out, uint32_t* end_i_out, uint32_t* end_j_out) {
     if (!ctx || !score_out) return PWA_E_INVALID;
-    pwa_batch* b = nullptr;
-    int rc = pwa_batch_create(ctx, mode, match, mismatch, gap, seq_bytes, seq_off, n_seq, pair_a, pair_b, n_pairs,
-                              (end_i_out || end_j_out) ? 1 : 0, &b);
-    if (rc != PWA_OK) return rc;
-    rc = pwa_batch_run(b, nullptr);
-    if (rc == PWA_OK) rc = pwa_batch_fetch(b, score_out, end_i_out, end_j_out);
-    pwa_batch_destroy(b);
-    return rc;
+    return scores_in_arena_chunks(ctx, seq_off, n_seq, pair_a, pair_b, n_pairs, score_out, end_i_out, end_j_out,
+                                  [&](const uint32_t* a, const uint32_t* b, uint64_t n, pwa_batch** out) {
+                                      return pwa_batch_create(ctx, mode, match, mismatch, gap, seq_bytes, seq_off, n_seq, a, b, n,
+                                                              (end_i_out || end_j_out) ? 1 : 0, out);
+                                  });
 }
 
+int pwa_distances(pwa_ctx* ctx, int match, int mismatch, int gap, const uint8_t* seq_bytes, const uint64_t* seq_off, uint32_t n_seq,
+                  const uint32_t* pair_a, const uint32_t* pair_b, uint64_t n_pairs, int32_t* dist_out) {
+    if (!ctx || !dist_out) return PWA_E_INVALID;
+    return scores_in_arena_chunks(ctx, seq_off, n_seq, pair_a, pair_b, n_pairs, dist_out, nullptr, nullptr,
+                                  [&](const uint32_t* a, const uint32_t* b, uint64_t n, pwa_batch** out) {
+                                      return pwa_nwdist_batch_create(ctx, match, mismatch, gap, seq_bytes, seq_off, n_seq, a, b, n, out);
+                                  });
+}
+
+int pwa_scores_affine(pwa_ctx* ctx, int match, int mismatch, int gap_open, int gap_extend, const uint8_t* seq_bytes,
+                      const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b, uint64_t n_pairs,
+                      int32_t* score_out) {
+    if (!ctx || !score_out) return PWA_E_INVALID;
+    return scores_in_arena_chunks(ctx, seq_off, n_seq, pair_a, pair_b, n_pairs, score_out, nullptr, nullptr,
+                                  [&](const uint32_t* a, const uint32_t* b, uint64_t n, pwa_batch** out) {
+                                      return pwa_affine_batch_create(ctx, match, mismatch, gap_open, gap_extend, seq_bytes, seq_off, n_seq,
+                                                                     a, b, n, out);
+                                  });
+}
+}  // extern "C"
+
 // ------------------------------------------------------------------------- full alignments
-} // extern "C" (reopened below): the shared implementation has C++ linkage
 // Full alignments of a pair list.  With `ops` the op lists come back (pwa_align_batch); without, only the
 // per-pair scores and -- with `overlap_out` -- the overlap lengths computed by the walk itself (pwa_overlaps).
 static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* seq_bytes,
@@ -1361,6 +1407,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     // (pair_fill.hip.h, PERM).  The table holds the two diagonal key constants: both must fit a signed byte.
     bool coded = false;
     uint8_t code_of[256];
+    bool dash_seen = false;
     {
         bool seen[256] = {false};
         for (uint32_t s = 0; s < n_seq; ++s)
@@ -1374,7 +1421,11 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         const int64_t kd_match = ((int64_t)match - gap) * 4 + 2, kd_mismatch = ((int64_t)mismatch - gap) * 4 + 2;
         coded = n_alpha <= 7 && kd_match <= 127 && kd_match >= -126 && kd_mismatch <= 127 && kd_mismatch >= -126 &&
                 !std::getenv("PWA_NO_PAIR_TABLE");
+        dash_seen = seen[(unsigned char)'-'];
     }
+    // overlapLongestExactMatch (hw2.cpp:269) does not count a column whose symbols are '-' -- also when the '-' is part
+    // of the input sequence itself: the walk needs the arena's value for that byte
+    const int32_t dash_sym = !dash_seen ? 0x100 : (coded ? (int32_t)code_of[(unsigned char)'-'] : (int32_t)'-');
     DevBuf arena;
     {
         std::vector<uint8_t> host_arena(arena_bytes, 0);
@@ -1397,9 +1448,9 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         longest_n = std::max(longest_n, slen(pair_a[k]));
         longest_sum = std::max(longest_sum, slen(pair_a[k]) + slen(pair_b[k]));
     }
-    if (!tb_range_ok(longest_sum, match, mismatch, gap))
-        return fail(ctx, PWA_E_CAPACITY, "scores times lengths exceed 2^28: outside the traceback engine's packed keys");
-    const PairGeom geom = choose_geom(longest_n);
+    // scores x lengths beyond the packed keys' 2^28: the plain int32 form, exact for anything the reference's int holds
+    const bool keyed = tb_range_ok(longest_sum, match, mismatch, gap) && !std::getenv("PWA_NO_KEYED_TB");
+    const PairGeom geom = choose_geom(longest_n, keyed);
     auto tb_band_bytes = [&](uint64_t n, uint64_t m) { return ::tb_band_bytes(n, m, geom.rl); };
     // pairs are processed in chunks whose traceback bands fit the free HBM
     size_t free_b = 0, total_b = 0;
@@ -1485,9 +1536,11 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         HIPC(ctx, hipMemcpy(d_res.p, res.data(), nc * sizeof(PairResult), hipMemcpyHostToDevice));
         mark("chunk descriptors");
         if (!pd.empty()) {
-            pl.perm = coded;
+            pl.perm = coded && keyed;
+            pl.keyed = keyed;
             int rc = pl.build(ctx, pd, match, mismatch, gap, geom);
             if (rc != PWA_OK) return rc;
+            pl.G.dash = dash_sym;
             mark("task list build + upload");
             if (dbg) std::fprintf(stderr, "[pwa] fill launch grid=%u pairs=%u tasks=%u band=%llu rows=%llu\n", pl.grid,
                                   pl.G.n_pairs, pl.G.n_tasks, (unsigned long long)band, (unsigned long long)pl.row_bytes);
@@ -1589,8 +1642,7 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     if (mode != PWA_MODE_NW && mode != PWA_MODE_SW) return fail(ctx, PWA_E_INVALID, "unknown mode");
     if ((n && !pattern) || (m && !text) || (!dp_out && !tb_out)) return fail(ctx, PWA_E_INVALID, "null input");
     if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
-    if (!tb_range_ok(n + m, match, mismatch, gap))
-        return fail(ctx, PWA_E_CAPACITY, "scores times lengths exceed 2^28: outside the traceback engine's packed keys");
+    const bool keyed = tb_range_ok(n + m, match, mismatch, gap) && !std::getenv("PWA_NO_KEYED_TB");
     const bool local = mode == PWA_MODE_SW;
     const uint64_t W = m + 1;
     // row 0 and column 0 exactly as the reference initialises them (hw2.cpp:119-136 / 193-194)
@@ -1604,7 +1656,7 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     }
     if (n == 0 || m == 0) return PWA_OK;
     HIPC(ctx, hipSetDevice(ctx->device));
-    const PairGeom geom = choose_geom(n);
+    const PairGeom geom = choose_geom(n, keyed);
     const uint64_t kRL = (uint64_t)geom.rl;
     const uint64_t band = tb_band_bytes(n, m, geom.rl);
     DevBuf d_pat, d_txt, d_band, d_sband, d_res;
@@ -1626,6 +1678,7 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     pd[0].sband = d_sband.as<int32_t>();
     pd[0].res = d_res.as<PairResult>();
     PairLaunch pl;
+    pl.keyed = keyed;
     int rc = pl.build(ctx, pd, match, mismatch, gap, geom);
     if (rc != PWA_OK) return rc;
     rc = pl.launch(ctx, ctx->stream, local, true, false, nullptr, true);

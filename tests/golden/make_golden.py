@@ -124,6 +124,30 @@ def main():
                 rnd.append(full_record(m, p, t, sc))
     out["random"] = rnd
 
+    # --- sequences that contain a literal '-': overlapLongestExactMatch (hw2.cpp:269) treats such a column as a gap
+    # column even though it came from the input, and prepareMDZString / the gapped strings carry the byte through
+    dash = []
+    dash_pairs = [(b"AC-GT", b"AC-GT"), (b"ACGA", b"ACGA"), (b"--------", b"--------"), (b"ACGT-ACGTACGT", b"ACGTACGT-ACGT"),
+                  (b"A-C-G-T-", b"-A-C-G-T"), (b"AAAA-AAAA", b"AAAAAAAA"), (b"-", b"-"), (b"-ACGT", b"ACGT-"),
+                  (b"ACGTACGTAC--GTACGTACGT", b"ACGTACGTAC--GTACGTACGT")]
+    for it in range(60):
+        alpha = rng.choice([b"ACGT-", b"A-", b"ACGTN-"])
+        n1, n2 = rng.randint(1, 200), rng.randint(1, 200)
+        p = bytes(rng.choice(alpha) for _ in range(n1))
+        t = bytes(rng.choice(alpha) for _ in range(n2))
+        if rng.random() < 0.6:   # related pair: long diagonal runs through '-' symbols
+            tt = bytearray(p)
+            for _ in range(rng.randint(0, 6)):
+                pos = rng.randrange(len(tt))
+                tt[pos] = rng.choice(alpha)
+            t = bytes(tt)
+        dash_pairs.append((p, t))
+    for (p, t) in dash_pairs:
+        for sc in [(1, -1, -1), (2, -3, -5), (1, 1, 1)]:
+            for m in ("nw", "sw"):
+                dash.append(full_record(m, p, t, sc))
+    out["dash"] = dash
+
     # --- generator KATs of SURVEY.md 8(d) (long strings hashed)
     kat = []
     for (n, m, sc) in [(64, 64, (1, -1, -1)), (150, 10000, (1, -1, -1)), (150, 10000, (2, -3, -5)),
@@ -131,8 +155,29 @@ def main():
                        (10000, 10000, (1, -1, -1))]:
         for mode in ("nw", "sw"):
             kat.append(hashed_record(mode, (1, 0, 0, n), (1, 1, 0, m), sc))
-    # a related (10 % diverged) long pair: realistic traceback path
     out["kat"] = kat
+
+    # --- scores x lengths beyond 2^28 (the engine's packed-key traceback form must hand over to its plain int32 form):
+    # the reference's recurrences work for anything its `int` holds (hw2.cpp:140-153, 206-222)
+    big = []
+    for (n, m, sc) in [(1500, 1600, (100000, -100000, -100000)), (1400, 1300, (1 << 20, -(1 << 19), -3)),
+                       (900, 2000, (7, -250000, -120000)), (3000, 200, (100000, -100000, 100000)),
+                       (1600, 1500, (-100000, 100000, -50000))]:
+        for mode in ("nw", "sw"):
+            big.append(hashed_record(mode, (3, 0, n, n), (3, 1, m, m), sc))
+    out["bigscore"] = big
+
+    # --- the real 16 x ~1000 bp file of the sibling program, all pairs, both modes, two scorings
+    real = read_fasta_py("/root/reference/Multiple_Sequence_Alignment/input161000.fasta")
+    assert len(real) == 16
+    c4r = {"file": "hw3_input161000.fasta", "n_seq": 16, "scorings": {}}
+    for sc in [(1, -1, -1), (5, -4, -4)]:
+        nw = [O.ref_align("nw", real[i], real[j], *sc)["score"] for i in range(16) for j in range(i + 1, 16)]
+        sw = [O.ref_align("sw", real[i], real[j], *sc)["score"] for i in range(16) for j in range(i + 1, 16)]
+        c4r["scorings"][",".join(map(str, sc))] = {"nw": nw, "sw": sw, "nw_sum": sum(nw), "nw_min": min(nw), "nw_max": max(nw),
+                                                    "sw_sum": sum(sw)}
+    assert c4r["scorings"]["1,-1,-1"]["nw_sum"] == 3013 and c4r["scorings"]["5,-4,-4"]["sw_sum"] == 102928
+    out["c4_real"] = c4r
 
     # --- batched score tables (scores-only kernels): small C3-shaped and C4-shaped batches
     pats = [O.gen(1, 0, i, 150) for i in range(96)]
@@ -165,7 +210,15 @@ def main():
         open(os.path.join(td, "two.fasta"), "w").write(">a\nACGT\n>b\nGGGG\n")
         open(os.path.join(td, "messy_p.fasta"), "wb").write(b">p1 \r\nACGT \r\nAC GT\t\r\n\r\n>empty\n>p2\nacgt\nACGT  \n>p3\nTTTT")
         open(os.path.join(td, "messy_t.fasta"), "wb").write(b"ACGTACGT\n>t2\n\nACGTACG\n>t3\nTTTAT\n")
-        files = {f: L(open(os.path.join(td, f), "rb").read()) for f in ("two.fasta", "messy_p.fasta", "messy_t.fasta")}
+        # the winner of -g changes when a '-' inside a sequence stops counting towards the overlap (hw2.cpp:269, 344)
+        open(os.path.join(td, "dash.fasta"), "w").write(">a\nAC-GT\n>b\nACGA\n")
+        open(os.path.join(td, "dash_p.fasta"), "w").write(">a\nACGT-ACGTACGT\n>b\nAC--GT\n>c\nTTTTT\n")
+        open(os.path.join(td, "dash_t.fasta"), "w").write(">a\nACGTACGT-ACGT\n>b\nAC--GT\n>c\nTTTAT\n")
+        # scores x lengths beyond 2^28 through the whole program (`hw2_amd -g -s 100000 ...` on 3 kb must not refuse)
+        open(os.path.join(td, "big_p.fasta"), "wb").write(b">a\n" + O.gen(5, 0, 0, 1500) + b"\n>b\n" + O.gen(5, 0, 1, 1700) + b"\n")
+        open(os.path.join(td, "big_t.fasta"), "wb").write(b">a\n" + O.gen(5, 1, 0, 1600) + b"\n>b\n" + O.gen(5, 1, 1, 1400) + b"\n")
+        files = {f: L(open(os.path.join(td, f), "rb").read()) for f in ("two.fasta", "messy_p.fasta", "messy_t.fasta", "dash.fasta",
+                                                                          "dash_p.fasta", "dash_t.fasta", "big_p.fasta", "big_t.fasta")}
         cases = [
             ["-g", "-p", "patterns.fasta", "-t", "texts.fasta", "-o", "out.txt", "-s", "1", "-1", "-1"],
             ["-l", "-p", "patterns.fasta", "-t", "texts.fasta", "-o", "out.txt", "-s", "1", "-1", "-1"],
@@ -183,6 +236,12 @@ def main():
             ["-l", "-p", "messy_p.fasta", "-t", "messy_t.fasta", "-o", "out.txt", "-s", "1", "-1", "-1"],
             ["-l", "-s", "1", "-1", "-1", "-o", "out.txt", "-t", "texts.fasta", "-p", "patterns.fasta"],
             ["-g", "-p", "patterns.fasta", "-t", "texts.fasta", "-o", "out.txt", "-s", "1", "-1"],
+            ["-g", "-p", "dash.fasta", "-t", "dash.fasta", "-o", "out.txt", "-s", "1", "-1", "-1"],
+            ["-l", "-p", "dash.fasta", "-t", "dash.fasta", "-o", "out.txt", "-s", "1", "-1", "-1"],
+            ["-g", "-p", "dash_p.fasta", "-t", "dash_t.fasta", "-o", "out.txt", "-s", "1", "-1", "-1"],
+            ["-g", "-p", "dash_p.fasta", "-t", "dash_t.fasta", "-o", "out.txt", "-s", "2", "-3", "-5"],
+            ["-g", "-p", "big_p.fasta", "-t", "big_t.fasta", "-o", "out.txt", "-s", "100000", "-100000", "-100000"],
+            ["-l", "-p", "big_p.fasta", "-t", "big_t.fasta", "-o", "out.txt", "-s", "100000", "-100000", "-100000"],
         ]
         for args in cases:
             outp = os.path.join(td, "out.txt")
@@ -196,7 +255,7 @@ def main():
 
     for key, val in out.items():
         with open(os.path.join(HERE, key + ".json"), "w") as f:
-            json.dump(val, f, indent=0 if key in ("random", "edge", "bundled") else 1)
+            json.dump(val, f, indent=0 if key in ("random", "edge", "bundled", "dash") else 1)
         print(key, os.path.getsize(os.path.join(HERE, key + ".json")), "bytes")
 
 

@@ -35,6 +35,23 @@ def test_library_has_gfx950_code_object():
     assert b"gfx950" in out and b"batch_scores_kernel" in out and b"pair_fill_kernel" in out
 
 
+def test_dropin_library_exports_the_reference_signatures():
+    """libhw2_dropin.so (INTEGRATION.md Option B): the two functions under the names a C++ caller compiled against
+    hw2.cpp:118 / 192 would link to (Itanium mangling of the reference's exact signatures) -- no compute call here."""
+    pkg = load_pkg()
+    so = os.path.join(os.path.dirname(pkg.LIB_PATH), "libhw2_dropin.so")
+    assert os.path.exists(so)
+    out = subprocess.run(["nm", "-D", "--defined-only", so], stdout=subprocess.PIPE).stdout.decode()
+    sig = "RKNSt7__cxx1112basic_stringIcSt11char_traitsIcESaIcEEES6_iii"   # (const std::string&, const std::string&, int, int, int)
+    assert "_Z30globalAlignmentNeedlemanWunsch" + sig in out
+    assert "_Z27localAlignmentSmithWaterman" + sig in out
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libhw2_ref.so")
+    if os.path.exists(ref_so):   # dev container: the compiled reference defines exactly these two symbols
+        ref = subprocess.run(["nm", "-D", "--defined-only", ref_so], stdout=subprocess.PIPE).stdout.decode()
+        for name in ("_Z30globalAlignmentNeedlemanWunsch" + sig, "_Z27localAlignmentSmithWaterman" + sig):
+            assert name in ref
+
+
 def _no_gpu():
     return not os.path.exists("/dev/kfd")
 

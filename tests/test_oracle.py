@@ -25,7 +25,7 @@ def check_full(rec, got):
     assert got["overlap"] == rec["overlap"]
 
 
-@pytest.mark.parametrize("name", ["bundled", "edge", "random"])
+@pytest.mark.parametrize("name", ["bundled", "edge", "random", "dash"])
 @pytest.mark.parametrize("compact", [False, True])
 def test_oracle_matches_reference_fixtures(name, compact):
     for rec in load_golden(name):
@@ -55,6 +55,22 @@ def test_oracle_kats():
         assert sha(got["aligned_pattern"]) == rec["aligned_pattern_sha256"]
         assert sha(got["aligned_reference"]) == rec["aligned_reference_sha256"]
         assert O.score(rec["mode"], p, t, *rec["scoring"])[0] == rec["score"]
+
+
+def test_oracle_big_scores_and_real_c4_file():
+    """fixtures added in round 2: scores x lengths beyond 2^28 (bigscore.json) and the sibling program's real 16 x 1000 bp
+    file (c4_real.json), both from the unmodified hw2.cpp"""
+    for rec in load_golden("bigscore"):
+        p, t = O.gen(*rec["gen_p"]), O.gen(*rec["gen_t"])
+        got = O.align(rec["mode"], p, t, *rec["scoring"], compact=True)
+        assert (got["score"], got["overlap"], len(got["aligned_pattern"])) == (rec["score"], rec["overlap"], rec["aligned_len"])
+        assert sha(got["cigar"]) == rec["cigar_sha256"] and sha(got["mdz"]) == rec["mdz_sha256"]
+    c4r = load_golden("c4_real")
+    seqs = O.read_fasta(os.path.join(GOLDEN, c4r["file"]))
+    for key, want in c4r["scorings"].items():
+        sc = tuple(int(x) for x in key.split(","))
+        for mode in ("nw", "sw"):
+            assert [O.score(mode, seqs[i], seqs[j], *sc)[0] for i in range(16) for j in range(i + 1, 16)] == want[mode]
 
 
 def test_survey_known_answers():

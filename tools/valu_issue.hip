@@ -1,0 +1,125 @@
+// valu_issue.hip -- issue cost of single VALU instructions on gfx950, measured two ways at 1 / 2 / 4 / 8 waves per SIMD:
+//   (a) in-kernel: s_memtime around the stream (shader-clock ticks), lane 0 of every wave, averaged  -> cycles per
+//       instruction as ONE wave sees them (at w waves per SIMD a wave gets 1/w of the SIMD: SIMD cost = that / w);
+//   (b) wall: HIP events around the launch, converted at the NOMINAL 2.4 GHz -> cycles per instruction and SIMD;
+//   and their quotient = the clock the chip actually held (ticks per second), so that neither figure rests on an assumed
+//   frequency.
+// Every stream is inline asm over 8 rotating registers (no instruction reads the result of the one before it), so the
+// compiler can neither fold nor reorder anything, and every launch runs >= 5 ms so that launch overhead is < 1 %.
+// Replaces the folded rows of profiles/r01_valu_rate_microbench.txt.
+//   hipcc --offload-arch=gfx950 -O2 -o tools/valu_issue tools/valu_issue.hip && tools/valu_issue
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define N_ITER 60000
+#define UNR 32
+#define BODY(txt, T)                                                                                                   \
+    T a[8];                                                                                                            \
+    for (int i = 0; i < 8; ++i) a[i] = (T)(threadIdx.x * 3 + i + seed);                                                \
+    unsigned long long t0, t1;                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");               \
+    for (int it = 0; it < N_ITER; ++it) {                                                                              \
+        _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                                              \
+            const int i = u & 7;                                                                                       \
+            asm volatile(txt : "=v"(a[i]) : "v"(a[(i + 3) & 7]), "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));            \
+        }                                                                                                              \
+    }                                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");               \
+    T r = 0;                                                                                                           \
+    for (int i = 0; i < 8; ++i) r += a[i];                                                                             \
+    out[blockIdx.x * 64 + threadIdx.x] = (int)r;                                                                       \
+    if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+#define OP(name, txt) \
+    __global__ __launch_bounds__(64) void name(int* out, unsigned long long* ticks, int seed) { BODY(txt, int) }
+#define OP64(name, txt) \
+    __global__ __launch_bounds__(64) void name(int* out, unsigned long long* ticks, int seed) { BODY(txt, long long) }
+
+OP(k_fma, "v_fma_f32 %0, %1, %2, %3")
+OP64(k_pkfma, "v_pk_fma_f32 %0, %1, %2, %3")
+OP64(k_pkadd32, "v_pk_add_f32 %0, %1, %2")
+OP(k_mulf, "v_mul_f32 %0, %1, %2")
+OP(k_addf, "v_add_f32 %0, %1, %2")
+OP(k_maxf, "v_max_f32 %0, %1, %2")
+OP(k_max3f, "v_max3_f32 %0, %1, %2, %3")
+OP(k_max3i, "v_max3_i32 %0, %1, %2, %3")
+OP(k_maxi, "v_max_i32 %0, %1, %2")
+OP(k_maxi16, "v_max_i16 %0, %1, %2")
+OP(k_maxu16, "v_max_u16 %0, %1, %2")
+OP(k_add, "v_add_u32 %0, %1, %2")
+OP(k_addc, "v_add_i32 %0, %1, %2 clamp")
+OP(k_subc, "v_sub_u32_e64 %0, %1, %2 clamp")
+OP(k_and, "v_and_b32 %0, %1, %2")
+OP(k_or, "v_or_b32 %0, %1, %2")
+OP(k_xor, "v_xor_b32 %0, %1, %2")
+OP(k_mov, "v_mov_b32 %0, %2")
+OP(k_sdwa, "v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
+OP(k_perm, "v_perm_b32 %0, %1, %2, %3")
+OP(k_pkmax, "v_pk_max_i16 %0, %1, %2")
+OP(k_pkadd, "v_pk_add_i16 %0, %1, %2")
+OP(k_pksubc, "v_pk_sub_u16 %0, %1, %2 clamp")
+OP(k_cndmask, "v_cndmask_b32 %0, %1, %2, vcc")
+OP(k_cmp, "v_cmp_eq_u32 vcc, %1, %2\n\tv_mov_b32 %0, %3")   // a compare needs a VGPR result to stay in the rotation: 2 instructions
+OP(k_lshl, "v_lshlrev_b32 %0, 3, %1")
+OP(k_lshladd, "v_lshl_add_u32 %0, %1, 2, %2")
+OP(k_add3, "v_add3_u32 %0, %1, %2, %3")
+OP(k_mad24, "v_mad_i32_i24 %0, %1, %2, %3")
+OP(k_cvtub, "v_cvt_f32_ubyte1 %0, %1")
+OP(k_dpp, "v_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf")
+OP(k_adddpp, "v_add_u32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf")
+OP(k_nop, "s_nop 0")
+
+typedef void (*kfn)(int*, unsigned long long*, int);
+int main() {
+    struct { const char* n; kfn f; int per; } t[] = {
+        {"v_fma_f32", k_fma, 1}, {"v_pk_fma_f32", k_pkfma, 1}, {"v_pk_add_f32", k_pkadd32, 1}, {"v_mul_f32", k_mulf, 1}, {"v_add_f32", k_addf, 1},
+        {"v_max_f32", k_maxf, 1}, {"v_max3_f32", k_max3f, 1}, {"v_max3_i32", k_max3i, 1}, {"v_max_i32", k_maxi, 1}, {"v_max_i16", k_maxi16, 1},
+        {"v_max_u16", k_maxu16, 1}, {"v_add_u32", k_add, 1}, {"v_add_i32 clamp", k_addc, 1}, {"v_sub_u32 clamp", k_subc, 1}, {"v_and_b32", k_and, 1},
+        {"v_or_b32", k_or, 1}, {"v_xor_b32", k_xor, 1}, {"v_mov_b32", k_mov, 1}, {"v_add_u32_sdwa sext(byte)", k_sdwa, 1}, {"v_perm_b32", k_perm, 1},
+        {"v_pk_max_i16", k_pkmax, 1}, {"v_pk_add_i16", k_pkadd, 1}, {"v_pk_sub_u16 clamp", k_pksubc, 1}, {"v_cndmask_b32 (vcc)", k_cndmask, 1},
+        {"v_cmp_eq_u32 + v_mov_b32", k_cmp, 2}, {"v_lshlrev_b32", k_lshl, 1}, {"v_lshl_add_u32", k_lshladd, 1}, {"v_add3_u32", k_add3, 1},
+        {"v_mad_i32_i24", k_mad24, 1}, {"v_cvt_f32_ubyte1", k_cvtub, 1}, {"v_mov_b32_dpp wave_shr:1", k_dpp, 1}, {"v_add_u32_dpp row_shr:1", k_adddpp, 1},
+        {"s_nop 0", k_nop, 1}};
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int max_blocks = prop.multiProcessorCount * 4 * 8;
+    int* d;
+    unsigned long long* dt;
+    hipMalloc(&d, (size_t)max_blocks * 64 * 4);
+    hipMalloc(&dt, (size_t)max_blocks * 8);
+    std::vector<unsigned long long> ht(max_blocks);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    printf("device %s, %d CUs.  Per instruction stream, at w = 1 / 2 / 4 / 8 waves per SIMD (every SIMD of the chip busy):\n", prop.gcnArchName,
+           prop.multiProcessorCount);
+    printf("  cyc/SIMD(ticks) = s_memtime ticks per instruction of one wave / w;  cyc/SIMD(wall@2.4) = wall time x 2.4 GHz per instruction / w ... and the\n"
+           "  clock they imply (GHz = ticks / wall).  %d x %d instructions per wave and launch.\n", N_ITER, UNR);
+    printf("%-28s | %-31s | %-31s | %s\n", "instruction", "cyc/SIMD (s_memtime ticks)", "cyc/SIMD (wall at 2.4 GHz)", "ms per launch (w=1), tick rate GHz (w=1, w=8)");
+    for (auto& e : t) {
+        double ct[4], cw[4], ghz[4], ms1 = 0;
+        int q = 0;
+        for (int wps : {1, 2, 4, 8}) {
+            const int blocks = prop.multiProcessorCount * 4 * wps;
+            hipLaunchKernelGGL(e.f, dim3(blocks), dim3(64), 0, 0, d, dt, 3);
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(e.f, dim3(blocks), dim3(64), 0, 0, d, dt, 3);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(ht.data(), dt, (size_t)blocks * 8, hipMemcpyDeviceToHost);
+            double sum = 0;
+            for (int b = 0; b < blocks; ++b) sum += (double)ht[b];
+            const double n_instr = (double)N_ITER * UNR * e.per;
+            ct[q] = sum / blocks / n_instr / wps;
+            cw[q] = ms * 1e-3 * 2.4e9 / n_instr / wps;
+            ghz[q] = (sum / blocks) / (ms * 1e-3) / 1e9;
+            if (wps == 1) ms1 = ms;
+            ++q;
+        }
+        printf("%-28s | %6.2f  %6.2f  %6.2f  %6.2f | %6.2f  %6.2f  %6.2f  %6.2f | %6.2f ms  %5.3f  %5.3f\n", e.n, ct[0], ct[1], ct[2], ct[3], cw[0], cw[1],
+               cw[2], cw[3], ms1, ghz[0], ghz[3]);
+    }
+    return 0;
+}
