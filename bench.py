@@ -338,6 +338,12 @@ def main():
         import torch   # noqa: F811
         import torch.distributed as dist   # noqa: F811
         os.environ["NCCL_DEBUG"] = os.environ.get("BENCH_NCCL_DEBUG", "WARN")   # keep RCCL's banner off stdout: ONE JSON line
+        if "RANK" not in os.environ:   # BENCH_FORCE_DIST=1 without a launcher: a one-rank group on this process
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]))
+            sk.close()
         if cpu:
             dist.init_process_group("gloo")
         else:

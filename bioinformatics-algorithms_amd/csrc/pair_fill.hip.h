@@ -57,6 +57,12 @@ __device__ __forceinline__ void tb_put_code(uint32_t& codes, int key) {
     if (R == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(codes) : "v"(key), "v"(3));
     if (R == 3) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(codes) : "v"(key), "v"(3));
 }
+// ... the step's first code: byte 0 = key & 3, bytes 1..3 = 0 (no zero-initialising move in front of it)
+__device__ __forceinline__ uint32_t tb_first_code(int key) {
+    uint32_t codes;
+    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD" : "=v"(codes) : "v"(key), "v"(3));
+    return codes;
+}
 __device__ __forceinline__ int tb_stored(int h, int gap, int prio_left) { return (int)((unsigned)h * 4u + (unsigned)gap * 4u + (unsigned)prio_left); }
 
 struct PairResult {
@@ -133,13 +139,16 @@ typedef PWA_GLOBAL int32_t g_i32;
 typedef PWA_GLOBAL const int32_t g_ci32;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// steps per stripe in the band layout: m + 63 anti-diagonal steps, rounded up to whole 16-step chunks (the fill always runs
+// whole chunks and stores every (step, lane) slot; slots of lanes outside the matrix are padding nobody reads)
+__host__ __device__ inline size_t band_steps(size_t m) { return (m + 63 + 15) & ~(size_t)15; }
 template <int RL>
 __device__ __forceinline__ size_t tb_index(int i, int j, int m) {   // i, j >= 1
     const int q = i - 1;
     const int s = q / (64 * RL);
     const int k = (q % (64 * RL)) / RL;
     const int r = q % RL;
-    const size_t T = (size_t)m + 63;
+    const size_t T = band_steps((size_t)m);
     return ((s * T + (size_t)(j - 1 + k)) * 64 + k) * RL + r;
 }
 
@@ -177,7 +186,7 @@ __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i
             for (int r = 0; r < RL; ++r) {
                 const int kd = PERM ? p_addw(dg, (int)(int8_t)(s4 >> (8 * r)))
                                     : p_addw(dg, (pc[r] == tch) ? cdm : cdx);   // hw2.cpp:142 / 208-211: diag + s
-                const int ku = p_addw(up, PU - PL);                       // up + gap
+                const int ku = r == 0 ? up : p_addw(up, PU - PL);         // up + gap (row 0: `bottom` arrives in that form)
                 const int kl = hl[r];                                     // left + gap
                 int k = max(kd, max(ku, kl));
                 if (LOCAL) k = max(k, (int)TB_STOP);                      // the zero floor wins every tie (hw2.cpp:214)
@@ -261,8 +270,10 @@ __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i
                 hnew[r] = h;
             }
         }
-        diag0 = up_in;
-        bottom = up;
+        // keyed form: `bottom` (and with it the rings and hand-off rows) carries the UP-candidate form H*4 + gap*4 + prio(up),
+        // what the row below feeds straight into its v_max3; diag0 stays in the left-candidate form the tables are built for
+        diag0 = (TB && KEYED) ? p_addw(up_in, TbCode<LOCAL>::LEFT - TbCode<LOCAL>::UP) : up_in;
+        bottom = (TB && KEYED) ? p_addw(up, TbCode<LOCAL>::UP - TbCode<LOCAL>::LEFT) : up;
     } else {
 #pragma unroll
         for (int r = 0; r < RL; ++r) hnew[r] = 0;
@@ -284,16 +295,180 @@ __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// kCH interior steps of the KEYED form, written out in issue order.
+//
+// A stripe is ONE wave alone on its SIMD, and the DP gives it one long dependent chain: row r's "up" candidate is row
+// r-1's fresh value, and row 0's comes from the lane above through a DPP move of the last row's value of the previous
+// step.  One wave alone issues an instruction every ~5.4 cycles whatever its class, and one that reads the result of the
+// instruction before it waits ~4 cycles longer (profiles/r02_valu_issue_microbench.txt).  hipcc schedules the
+// straightforward source as a bare chain -- it hoists the step's independent work (text / row rotations, table lookups)
+// in front of it -- so a step cost ~7.4 cycles x its instruction count (r01: 275 cycles for 37 instructions).  Here
+//  (1) the chain is 3 instructions per row, v_max3 -> v_and -> v_add: the up-candidate of the next row is built from
+//      `base` next to, not after, the row's own stored value, and values travel between lanes / stripes in that form;
+//  (2) every chain instruction is followed by independent work that fits behind it -- the NEXT row's diagonal candidate,
+//      this row's code byte and stored value, the per-step chores -- and __builtin_amdgcn_sched_barrier keeps hipcc from
+//      regrouping them;
+//  (3) lane 0's inputs (the staged row above the stripe and the staged text) are picked out of the chunk's staging
+//      registers by a row_shl:q DPP write into lane 0 of the very register the wave_shr:1 move then fills for lanes
+//      1..63 (q is a compile-time constant: the chunk is fully unrolled) -- no copy, no rotation of the staged vectors;
+//  (4) lane 63 writes its bottom-row value straight into the LDS ring of the stripe below (one ds_write per step, the
+//      other lanes hit a dump line) instead of shifting it through a collector register.
+#define PWA_SB() __builtin_amdgcn_sched_barrier(0)
+constexpr int kCHsteps = 16;
+template <int Q> struct StepIndex { static constexpr int value = Q; };
+template <int Q, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (Q < N) {
+        f(StepIndex<Q>{});
+        static_for<Q + 1, N>(f);
+    }
+}
+// dst lane 0 <- v lane Q (Q in 0..15); lanes 4, 8, 12 are written too (bank 0 of row 0) and are overwritten by the wave_shr:1
+// move that follows; all other lanes keep `dst`
+template <int Q>
+__device__ __forceinline__ int dpp_pick_lane0(int dst, int v) {
+    if constexpr (Q == 0) return __builtin_amdgcn_update_dpp(dst, v, 0xE4 /* quad_perm:[0,1,2,3] */, 0x1, 0x1, false);
+    else return __builtin_amdgcn_update_dpp(dst, v, 0x100 + Q /* row_shl:Q */, 0x1, 0x1, false);
+}
+// lanes 1..63 <- lane k-1 of v; lane 0 keeps dst
+__device__ __forceinline__ int dpp_fill_shr1(int dst, int v) { return __builtin_amdgcn_update_dpp(dst, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+
+// GUARD: the chunk touches steps at which some lanes are outside the matrix (the first 63 steps of a stripe, while the lanes
+// come in one per step, and the last ones, while they leave): the same code, with a lane's state frozen while it is outside
+// -- one compare and RL + 2 selects per step.  (r01 ran those steps through a predicated, rolled loop at ~2.7x the cost of an
+// interior step; as every stripe waits for the first ~80 steps of the stripe above, that ramp was the whole pipeline's
+// start-up lag: 220 interior steps per stripe instead of 80 [gpu, tools/pair_scaling.py].)
+template <int RL, bool LOCAL, bool SBAND, bool PERM, bool GUARD>
+__device__ __forceinline__ void keyed_chunk(const int t0, const int lane, const int m, const int (&pc)[RL], int (&hl)[RL], int& diag0, int& bottom,
+                                            int& tch, const int topv, const int tcv, int (&bs)[RL], int (&bj)[RL], const int tab_lo,
+                                            const int tab_hi, const int cl, g_u8* tbs, g_i32* sbs, int* ring_out) {
+    constexpr int PU = TbCode<LOCAL>::UP, PL = TbCode<LOCAL>::LEFT;
+    const int cu = p_addw(cl, PU - PL);
+    // band pointers of this lane at step t0: the unrolled steps store at immediate offsets from them
+    PWA_GLOBAL uint32_t* const tb4 = (g_u32*)tbs + (size_t)t0 * 64 + lane;
+    PWA_GLOBAL uint16_t* const tb2 = (PWA_GLOBAL uint16_t*)tbs + (size_t)t0 * 64 + lane;
+    g_u8* const tb1 = tbs + ((size_t)t0 * 64 + lane) * RL;
+    g_i32* const sb = SBAND ? sbs + ((size_t)t0 * 64 + lane) * RL : nullptr;
+    auto diag_cand = [&](int r, int dg, uint32_t sc4, int sym) -> int {   // hw2.cpp:142 / 208-211: diag + s, as a key
+        return PERM ? p_addw(dg, (int)(int8_t)(sc4 >> (8 * r))) : p_addw(dg, (pc[r] == sym) ? tab_lo : tab_hi);   // non-PERM: the two key constants
+    };
+    // text symbol and table scores of the chunk's first step (later steps get theirs one step ahead, as fillers)
+    int tn = dpp_fill_shr1(dpp_pick_lane0<0>(tch, tcv), tch);
+    uint32_t s4 = PERM ? __builtin_amdgcn_perm((uint32_t)tab_hi, (uint32_t)tab_lo, (uint32_t)pc[0] ^ (uint32_t)tn) : 0u;
+    int upv = dpp_pick_lane0<0>(bottom, topv);   // lane 0 of the first step's "row above"
+    int tdead = tch;                             // a register whose value is dead: destination of the next text pick
+    constexpr int P = 3 * RL;                    // filler slots of a step: after each of the 3 chain instructions of each row
+    constexpr int F_FILL = P > 3 ? 3 : P - 1;    // slot of the wave_shr:1 half of the next text symbol: >= 3 instructions after its lane-0 pick
+    static_for<0, kCHsteps>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr bool more = q + 1 < kCHsteps;
+        const int j = t0 + q - lane + 1;
+        const bool act = !GUARD || (unsigned)(j - 1) < (unsigned)m;   // this lane's column is inside the matrix
+        // ---- chain: the row above (lane k-1's last row of the previous step; lane 0: the staged row, already in place)
+        const int up_in = dpp_fill_shr1(upv, bottom);
+        int kd[RL], t3[RL], hn[RL], hsb[RL];
+        kd[0] = diag_cand(0, diag0, s4, tn);
+        if (LOCAL) t3[0] = max(max(kd[0], hl[0]), (int)TB_STOP);   // everything but the up candidate: off the chain
+        if (RL > 1) kd[1] = diag_cand(1, hl[0], s4, tn);
+        PWA_SB();
+        int up = up_in, tn2 = tn;
+        uint32_t codes, s4n = s4, xn = 0;
+        bool have_x = false, have_s = false;
+        auto chores = [&](int slot) {   // the next step's text symbol and table scores, spread over the filler slots
+            if constexpr (more) {
+                if (slot == 0) tn2 = dpp_pick_lane0<q + 1>(tdead, tcv);         // lane 0 of it, into a dead register ...
+                if (slot == F_FILL) tn2 = dpp_fill_shr1(tn2, tn);                // ... lanes 1..63 of it
+                if (PERM && slot == F_FILL + 1) {
+                    xn = (uint32_t)pc[0] ^ (uint32_t)tn2;
+                    have_x = true;
+                }
+                if (PERM && slot == F_FILL + 2) {
+                    s4n = __builtin_amdgcn_perm((uint32_t)tab_hi, (uint32_t)tab_lo, xn);
+                    have_s = true;
+                }
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {
+            const int k = LOCAL ? max(t3[r], up) : max(max(kd[r], up), hl[r]);   // chain (hw2.cpp:142-153 / 211-222 in one v_max)
+            if (LOCAL && r + 1 < RL) t3[r + 1] = max(max(kd[r + 1], hl[r + 1]), (int)TB_STOP);
+            if (r + 2 < RL) kd[r + 2] = diag_cand(r + 2, hl[r + 1], s4, tn);
+            chores(3 * r);
+            PWA_SB();
+            const int base = k & ~3;                                             // chain
+            if (r == 0) codes = tb_first_code(k);
+            if (r == 1) tb_put_code<1>(codes, k);
+            if (r == 2) tb_put_code<2>(codes, k);
+            if (r == 3) tb_put_code<3>(codes, k);
+            if (r == 0) {
+                const int d0 = p_addw(up_in, PL - PU);                           // chore: the next step's diagonal source of row 0
+                diag0 = act ? d0 : diag0;
+                asm volatile("" : "+v"(diag0));                                  // (kept as its own add: folded into the next step it keeps up_in alive)
+            }
+            chores(3 * r + 1);
+            if (SBAND) hsb[r] = k >> 2;
+            PWA_SB();
+            up = p_addw(base, cu);                                               // chain: what the row below / the lane below takes
+            hn[r] = p_addw(base, cl);                                            // what the next column (left) and the diagonal take
+            chores(3 * r + 2);
+            if (LOCAL) {
+                if (act && base > bs[r]) {                                       // hw2.cpp:225-229 (bs holds H * 4)
+                    bs[r] = base;
+                    bj[r] = j;
+                }
+            }
+            PWA_SB();
+        }
+        bottom = act ? up : bottom;
+        if constexpr (more && PERM) {
+            if (!have_x) xn = (uint32_t)pc[0] ^ (uint32_t)tn2;
+            if (!have_s) s4n = __builtin_amdgcn_perm((uint32_t)tab_hi, (uint32_t)tab_lo, xn);
+        }
+        // lane 0 of the next step's row above, into a dead register (this step's first diagonal candidate); together with the
+        // stores below it also separates the chain's last add from the DPP move that reads it (VALU write -> DPP read)
+        if constexpr (more) upv = dpp_pick_lane0<q + 1>(kd[0], topv);
+        ring_out[q] = bottom;             // lane 63: column t - 63 of the stripe's bottom row, into the ring of the stripe below
+        if (RL == 4) {
+            tb4[q * 64] = codes;
+        } else if (RL == 2) {
+            tb2[q * 64] = (uint16_t)codes;
+        } else {
+#pragma unroll
+            for (int r = 0; r < RL; ++r) tb1[q * 64 * RL + r] = (uint8_t)(codes >> (8 * r));
+        }
+        if (SBAND) {
+#pragma unroll
+            for (int r = 0; r < RL; ++r) sb[q * 64 * RL + r] = hsb[r];
+        }
+#pragma unroll
+        for (int r = 0; r < RL; ++r) hl[r] = act ? hn[r] : hl[r];
+        tdead = tn;
+        tn = tn2;
+        s4 = s4n;
+        PWA_SB();
+    });
+    tch = tn;
+}
+
 #ifndef PWA_STEP_UNROLL
 #define PWA_STEP_UNROLL 8   // [gpu] C5 fill: 4 -> 21.1 ms, 8 -> 20.1 ms, 16 -> 23.2 ms
 #endif
 constexpr int kCH = 16;      // steps per hand-off chunk
-constexpr int kRing = 128;   // columns per LDS row ring (8 chunks)
+constexpr int kRing = 512;   // columns per LDS row ring (32 chunks)
+constexpr int kTrip = 256;   // columns the helper wave moves per trip and direction (4 per lane)
+// [gpu, r02] with 64 columns per trip the helper was the whole pipeline's clock: every trip costs three dependent HBM
+// round trips (counter poll -> row loads; row stores -> vmcnt(0) -> counter store), ~7 us, i.e. ~115 ns = 275 cycles per
+// column -- exactly the "step cost" of r01, whatever the compute waves did (RL = 2 or 4, NW or SW, 31 or 37 instructions)
+// column c of a stripe's bottom row is produced by lane 63 at step t = c + 63: slot = t % kRing, so that the 16 columns of one
+// hand-off chunk (t0 a multiple of 16) are 16 consecutive slots that never wrap
+__device__ __forceinline__ int ring_slot(int c) { return (c + 63) & (kRing - 1); }
 constexpr int kTRing = 4096; // text bytes staged in LDS
 
 template <int W>
 struct WgShared {
     int ring[W + 1][kRing];       // ring[w]: row above compute wave w; ring[W]: bottom row of the last wave
+    int dump[W][64 + kCH];        // keyed interior chunks: where lanes 0..62 (and lane 63 of a stripe without a consumer) put their per-step ring write
     uint8_t text[kTRing];
     uint32_t ready[W + 1];        // columns written into ring[w]
     uint32_t taken[W + 1];        // columns consumed from ring[w]
@@ -345,19 +520,30 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                 const bool done_in = kin >= m, done_out = !bot_global || kout >= m;
                 if (done_in && done_out) break;
                 bool progress = false;
-                if (!done_in) {   // ---- stage text + the row above wave 0, up to 64 columns per trip
+                if (!done_in) {   // ---- stage text + the row above wave 0, up to kTrip columns per trip
                     int lim = min(m, min((int)lds_peek(&sh.taken[0]) + kRing, (int)lds_peek(&sh.taken[wl]) + kTRing));
                     if (top_global) lim = min(lim, (int)__hip_atomic_load(prog_in, PWA_RLX_AGENT));   // sc1 poll
-                    const int hi = min(lim, kin + 64);
+                    const int hi = min(lim, kin + kTrip);
                     if (hi > kin) {
-                        const int c = kin + lane;
-                        if (c < hi) {
-                            int v;
-                            if (top_global) v = __hip_atomic_load(rin + c, PWA_RLX_AGENT);   // sc1: issued after the poll's value is known
-                            else v = LOCAL ? 0 : p_mulw(c + 1, gap);                         // dp[0][j], hw2.cpp:131-136
-                            if (TBK && !top_global) v = tb_stored(v, gap, TbCode<LOCAL>::LEFT);
-                            sh.ring[0][c % kRing] = v;
-                            sh.text[c % kTRing] = txt[c];
+                        int v[kTrip / 64], tc[kTrip / 64];
+#pragma unroll
+                        for (int u = 0; u < kTrip / 64; ++u) {   // all loads of the trip in flight together
+                            const int c = kin + u * 64 + lane;
+                            v[u] = tc[u] = 0;
+                            if (c < hi) {
+                                if (top_global) v[u] = __hip_atomic_load(rin + c, PWA_RLX_AGENT);   // sc1: issued after the poll's value is known
+                                else v[u] = LOCAL ? 0 : p_mulw(c + 1, gap);                         // dp[0][j], hw2.cpp:131-136
+                                tc[u] = txt[c];
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < kTrip / 64; ++u) {
+                            const int c = kin + u * 64 + lane;
+                            if (c < hi) {
+                                if (TBK && !top_global) v[u] = tb_stored(v[u], gap, TbCode<LOCAL>::UP);   // the form `bottom` travels in
+                                sh.ring[0][ring_slot(c)] = v[u];
+                                sh.text[c % kTRing] = (uint8_t)tc[u];
+                            }
                         }
                         lds_post(&sh.ready[0], (uint32_t)hi);
                         lds_post(&sh.txt_ready, (uint32_t)hi);
@@ -366,10 +552,13 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                     }
                 }
                 if (!done_out) {   // ---- publish the bottom row of the last wave
-                    const int hi = min((int)lds_peek(&sh.ready[W]), kout + 64);
+                    const int hi = min((int)lds_peek(&sh.ready[W]), kout + kTrip);
                     if (hi > kout) {
-                        const int c = kout + lane;
-                        if (c < hi) __hip_atomic_store(rout + c, sh.ring[W][c % kRing], PWA_RLX_AGENT);   // sc1 (write-through)
+#pragma unroll
+                        for (int u = 0; u < kTrip / 64; ++u) {
+                            const int c = kout + u * 64 + lane;
+                            if (c < hi) __hip_atomic_store(rout + c, sh.ring[W][ring_slot(c)], PWA_RLX_AGENT);   // sc1 (write-through)
+                        }
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   // only this wave's own stores
                         if (lane == 0) __hip_atomic_store(prog_out, (uint32_t)hi, PWA_RLX_AGENT);
                         lds_post(&sh.taken[W], (uint32_t)hi);
@@ -404,8 +593,9 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
             }
             int diag0 = LOCAL ? 0 : p_mulw(i_first - 1, gap);           // dp[i_first-1][0]
             if (TBK) diag0 = tb_stored(diag0, gap, TbCode<LOCAL>::LEFT);
-            g_u8* tbs = TB ? (g_u8*)(P.tb + (size_t)s * T * 64 * RL) : nullptr;
-            g_i32* sbs = SBAND ? (g_i32*)(P.sband + (size_t)s * T * 64 * RL) : nullptr;
+            const size_t Tb = band_steps((size_t)m);
+            g_u8* tbs = TB ? (g_u8*)(P.tb + (size_t)s * Tb * 64 * RL) : nullptr;
+            g_i32* sbs = SBAND ? (g_i32*)(P.sband + (size_t)s * Tb * 64 * RL) : nullptr;
             PWA_GLOBAL PairResult* res = (PWA_GLOBAL PairResult*)P.res;
             // traceback kernels: stripe_step takes the key constants instead of the three scores
             int a_match = TBK ? (int)(((unsigned)match - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - TbCode<LOCAL>::LEFT)) : match;
@@ -424,24 +614,65 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
             int* rout = sh.ring[wave + 1];
             int bottom = 0, tch = 0, coll = 0;
             bool failed = false;
+            // keyed fills look one chunk ahead: flags and staged values of chunk ch + 1 are read (not waited for) before chunk ch
+            // runs, so that a stripe that is not waiting for its producer -- the first one sets the pace of all -- pays no LDS
+            // round trips between chunks; when the flags were not there yet the chunk start falls back to the polling loop
+            int p_topv = 0, p_tcv = 0;
+            uint32_t p_ready = 0, p_txt = 0, p_taken = 0;
             for (int ch = 0; ch < n_chunks; ++ch) {
                 const int t0 = ch * CH;
                 // ---- wait for the row above and the text of columns t0 .. t0+CH-1, then take them
                 const uint32_t need = (uint32_t)min(m, t0 + CH);
-                for (uint32_t spins = 0; !failed && (lds_peek(&sh.ready[wave]) < need || lds_peek(&sh.txt_ready) < need);) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > spin_limit) failed = true;
-                }
                 const int c0 = t0 + lane;
                 int topv = 0, tcv = 0;
-                if (lane < CH && c0 < m) {
-                    topv = rin[c0 % kRing];
-                    tcv = sh.text[c0 % kTRing];
-                    if (PERM) tcv *= 0x01010101;   // the text symbol travels down the lanes already splatted
+                if (TBK && __builtin_amdgcn_readfirstlane(p_ready) >= need && __builtin_amdgcn_readfirstlane(p_txt) >= need) {
+                    topv = p_topv;
+                    tcv = p_tcv;
+                } else {
+                    for (uint32_t spins = 0; !failed && (lds_peek(&sh.ready[wave]) < need || lds_peek(&sh.txt_ready) < need);) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > spin_limit) failed = true;
+                    }
+                    if (lane < CH && c0 < m) {
+                        topv = rin[ring_slot(c0)];
+                        tcv = sh.text[c0 % kTRing];
+                        if (PERM) tcv *= 0x01010101;   // the text symbol travels down the lanes already splatted
+                    }
                 }
                 lds_post(&sh.taken[wave], need);
                 const bool interior = t0 >= 63 && t0 + CH < m;   // every lane inside the matrix, last column not touched
-                if (interior) {
+                if (TBK) {
+                    static_assert(kCHsteps == kCH, "keyed_chunk runs one hand-off chunk");
+                    // the chunk's 16 bottom-row columns t0-63 .. t0-48 go into the ring step by step: make room first (the
+                    // unclamped column count: lane 63 also writes while it is outside the matrix, and those slots must be free)
+                    if (has_out && (t0 - 63 + CH) - (int)__builtin_amdgcn_readfirstlane(p_taken) > kRing)   // (a stale count only errs on the safe side)
+                        for (uint32_t spins = 0; !failed && (t0 - 63 + CH) - (int)lds_peek(&sh.taken[wave + 1]) > kRing;) {   // ring full
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > spin_limit) failed = true;
+                        }
+                    if (ch + 1 < n_chunks) {   // look ahead: chunk ch + 1 (flags first, then the values they cover: LDS runs in order)
+                        p_ready = lds_peek(&sh.ready[wave]);
+                        p_txt = lds_peek(&sh.txt_ready);
+                        if (has_out) p_taken = lds_peek(&sh.taken[wave + 1]);
+                        const int c1 = c0 + CH;
+                        p_topv = p_tcv = 0;
+                        if (lane < CH && c1 < m) {
+                            p_topv = rin[ring_slot(c1)];
+                            p_tcv = sh.text[c1 % kTRing];
+                            if (PERM) p_tcv *= 0x01010101;
+                        }
+                    }
+                    int* const ring_out = (has_out && lane == 63) ? rout + ring_slot(t0 - 63) : sh.dump[wave] + lane;
+                    if (interior)
+                        keyed_chunk<RL, LOCAL, SBAND, PERM, false>(t0, lane, m, pc, hl, diag0, bottom, tch, topv, tcv, bs, bj, a_match, a_mismatch,
+                                                                   a_gap, tbs, sbs, ring_out);
+                    else
+                        keyed_chunk<RL, LOCAL, SBAND, PERM, true>(t0, lane, m, pc, hl, diag0, bottom, tch, topv, tcv, bs, bj, a_match, a_mismatch,
+                                                                  a_gap, tbs, sbs, ring_out);
+                    const int hi = min(m, t0 - 63 + CH);
+                    if (has_out && hi > 0) lds_post(&sh.ready[wave + 1], (uint32_t)hi);   // after the chunk's ring writes (one wave: in order)
+                    continue;
+                } else if (interior) {
 #pragma unroll PWA_STEP_UNROLL
                     for (int q = 0; q < CH; ++q)
                         stripe_step<RL, LOCAL, TB, SBAND, false, PERM, KEYED>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
@@ -464,12 +695,19 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                             if (++spins > spin_limit) failed = true;
                         }
                         const int c = t0 - 63 + (lane - (64 - CH));
-                        if (lane >= 64 - CH && c >= 0 && c < m) rout[c % kRing] = coll;
+                        if (lane >= 64 - CH && c >= 0 && c < m) rout[ring_slot(c)] = coll;
                         lds_post(&sh.ready[wave + 1], (uint32_t)hi);
                     }
                 }
             }
             if (failed && lane == 0) __hip_atomic_store((g_u32*)(G.queue + 1), 1u, PWA_RLX_AGENT);
+            if (TBK && !LOCAL) {
+                // dp[n][m] (hw2.cpp:186): a lane's state freezes when it leaves the matrix, so the row that holds row n still has
+                // its last column's stored value: H * 4 + gap * 4 + prio(left)
+#pragma unroll
+                for (int r = 0; r < RL; ++r)
+                    if (i_first + r == n) res->score = (int)((unsigned)hl[r] - (unsigned)a_gap) >> 2;
+            }
 
             if (LOCAL) {
                 // per-lane reduction over row slots, then over the wave: max score, then smallest i
@@ -521,7 +759,7 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
     if (pid >= G.n_pairs) return;
     const PairDesc P = G.pairs[pid];
     const int m = P.m;
-    const size_t T = (size_t)m + 63;
+    const size_t T = band_steps((size_t)m);
     g_cu8* tb = (g_cu8*)P.tb;
     g_u8* ops = (g_u8*)P.ops;
     PWA_GLOBAL PairResult* res = (PWA_GLOBAL PairResult*)P.res;

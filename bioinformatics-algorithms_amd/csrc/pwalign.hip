@@ -173,7 +173,7 @@ inline int32_t wrap_mul(int64_t a, int32_t b) { return (int32_t)((uint32_t)a * (
 struct PairGeom {
     int rl, w;
 };
-PairGeom choose_geom(uint64_t max_n, bool keyed = true) {
+PairGeom choose_geom(uint64_t max_n, bool keyed = true, bool keyed_tb = false) {
     PairGeom g{max_n <= 32768 ? 2 : 4, 4};   // [gpu] 10k x 10k: RL=2 2.27 ms vs RL=4 2.52; 100k x 100k: RL=4 20.9 ms vs RL=2 22.0
     // 129..256 rows: ONE 256-row stripe (W = 1, 8 workgroups per CU) instead of two 128-row stripes in a 4-stripe
     // workgroup with two idle waves; [gpu] 4096 pairs 150 x 10k: fill 8.2 -> 7.3 ms, with the score band 12.1 -> 10.4 ms
@@ -181,6 +181,9 @@ PairGeom choose_geom(uint64_t max_n, bool keyed = true) {
     if (const char* e = std::getenv("PWA_FORCE_RL")) g.rl = std::atoi(e) == 2 ? 2 : 4;   // experiments only
     if (!keyed) g.rl = 4;   // the plain int32 traceback form exists for RL = 4 only (pair_kernels.hip)
     if ((max_n + 64 * g.rl - 1) / (64 * g.rl) <= 1) g.w = 1;
+    // (W = 8 was built and measured in r02: nine waves on a CU's four SIMDs share issue slots, a step goes from 197 to 317
+    // cycles -- a workgroup lives on one CU, so four compute waves is the most that keeps one stripe per SIMD)
+    (void)keyed_tb;
     if (const char* e = std::getenv("PWA_FORCE_W")) g.w = std::atoi(e) == 1 ? 1 : 4;
     return g;
 }
@@ -191,7 +194,7 @@ pair_kernel_t pair_tb_fn(PairGeom g, bool local, int walk) { return pair_traceba
 
 size_t tb_band_bytes(uint64_t n, uint64_t m, int rl) {
     const uint64_t stripes = (n + 64 * rl - 1) / (64 * rl);
-    return (size_t)(stripes * (m + 63) * 64 * rl);
+    return (size_t)(stripes * band_steps(m) * 64 * rl);
 }
 
 // Device-side state of one launch of the wavefront (pair) engine: pair descriptors, the global
@@ -1450,7 +1453,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     }
     // scores x lengths beyond the packed keys' 2^28: the plain int32 form, exact for anything the reference's int holds
     const bool keyed = tb_range_ok(longest_sum, match, mismatch, gap) && !std::getenv("PWA_NO_KEYED_TB");
-    const PairGeom geom = choose_geom(longest_n, keyed);
+    const PairGeom geom = choose_geom(longest_n, keyed, true);
     auto tb_band_bytes = [&](uint64_t n, uint64_t m) { return ::tb_band_bytes(n, m, geom.rl); };
     // pairs are processed in chunks whose traceback bands fit the free HBM
     size_t free_b = 0, total_b = 0;
@@ -1656,7 +1659,7 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     }
     if (n == 0 || m == 0) return PWA_OK;
     HIPC(ctx, hipSetDevice(ctx->device));
-    const PairGeom geom = choose_geom(n, keyed);
+    const PairGeom geom = choose_geom(n, keyed, true);
     const uint64_t kRL = (uint64_t)geom.rl;
     const uint64_t band = tb_band_bytes(n, m, geom.rl);
     DevBuf d_pat, d_txt, d_band, d_sband, d_res;
@@ -1693,7 +1696,7 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     // band codes are tie-break priorities (pair_fill.hip.h): global up 0, left 1, diag 2; local left 0, up 1, diag 2, floor 3
     static const char kCodeNW[4] = {'u', 'l', 'd', 'd'}, kCodeSW[4] = {'l', 'u', 'd', '0'};   // hw2.cpp:145-153 / 214-222
     const char* const kCode = local ? kCodeSW : kCodeNW;
-    const uint64_t T = m + 63;
+    const uint64_t T = band_steps(m);
     for (uint64_t i = 1; i <= n; ++i) {
         const uint64_t q = i - 1, st = q / (64 * kRL), k = (q % (64 * kRL)) / kRL, r = q % kRL;
         for (uint64_t j = 1; j <= m; ++j) {

@@ -57,7 +57,7 @@ OP(k_perm, "v_perm_b32 %0, %1, %2, %3")
 OP(k_pkmax, "v_pk_max_i16 %0, %1, %2")
 OP(k_pkadd, "v_pk_add_i16 %0, %1, %2")
 OP(k_pksubc, "v_pk_sub_u16 %0, %1, %2 clamp")
-OP(k_cndmask, "v_cndmask_b32 %0, %1, %2, vcc")
+OP(k_cndmask, "v_cndmask_b32_e64 %0, %1, %2, s[2:3]")   // the kernarg pointer pair as an arbitrary lane mask
 OP(k_cmp, "v_cmp_eq_u32 vcc, %1, %2\n\tv_mov_b32 %0, %3")   // a compare needs a VGPR result to stay in the rotation: 2 instructions
 OP(k_lshl, "v_lshlrev_b32 %0, 3, %1")
 OP(k_lshladd, "v_lshl_add_u32 %0, %1, 2, %2")
@@ -68,6 +68,30 @@ OP(k_dpp, "v_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf")
 OP(k_adddpp, "v_add_u32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf")
 OP(k_nop, "s_nop 0")
 
+// dependent chains (every instruction reads the result of the one before it) and chains diluted with independent fillers:
+// what ONE wave alone on its SIMD sustains -- the single-pair fill kernel's regime (one stripe = one wave per SIMD)
+#define OPDEP(name, txt) \
+    __global__ __launch_bounds__(64) void name(int* out, unsigned long long* ticks, int seed) { \
+        int a[8]; for (int i = 0; i < 8; ++i) a[i] = threadIdx.x * 3 + i + seed; \
+        unsigned long long t0, t1; \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory"); \
+        for (int it = 0; it < N_ITER; ++it) { _Pragma("unroll") for (int u = 0; u < UNR / 4; ++u) { \
+            asm volatile(txt : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]) : "v"(a[6]), "v"(a[7])); } } \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory"); \
+        int r = 0; for (int i = 0; i < 8; ++i) r += a[i]; out[blockIdx.x * 64 + threadIdx.x] = r; \
+        if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0; }
+// %0 is the chain register; %1..%5 are filler registers; %6, %7 read-only.  Each macro body = 4 chain instructions (+ fillers).
+OPDEP(d_add, "v_add_u32 %0, %0, %6\n\tv_add_u32 %0, %0, %7\n\tv_add_u32 %0, %0, %6\n\tv_add_u32 %0, %0, %7")
+OPDEP(d_and, "v_and_b32 %0, %0, %6\n\tv_or_b32 %0, %0, %7\n\tv_and_b32 %0, %0, %6\n\tv_or_b32 %0, %0, %7")
+OPDEP(d_max3, "v_max3_i32 %0, %0, %6, %7\n\tv_max3_i32 %0, %0, %7, %6\n\tv_max3_i32 %0, %0, %6, %7\n\tv_max3_i32 %0, %0, %7, %6")
+OPDEP(d_sdwa, "v_add_u32_sdwa %0, %0, sext(%6) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\tv_add_u32_sdwa %0, %0, sext(%7) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\tv_add_u32_sdwa %0, %0, sext(%6) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\tv_add_u32_sdwa %0, %0, sext(%7) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
+OPDEP(d_dpp, "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf")
+// the fill kernel's chain: max3 -> and -> add, undiluted; then with one / two independent fillers after every chain instruction
+OPDEP(d_mix, "v_max3_i32 %0, %0, %6, %7\n\tv_and_b32 %0, %0, %6\n\tv_add_u32 %0, %0, %7\n\tv_max3_i32 %0, %0, %7, %6")
+OPDEP(d_mix1, "v_max3_i32 %0, %0, %6, %7\n\tv_add_u32 %1, %1, %6\n\tv_and_b32 %0, %0, %6\n\tv_add_u32 %2, %2, %6\n\tv_add_u32 %0, %0, %7\n\tv_add_u32 %3, %3, %6\n\tv_max3_i32 %0, %0, %7, %6\n\tv_add_u32 %4, %4, %6")
+OPDEP(d_mix1s, "v_max3_i32 %0, %0, %6, %7\n\tv_perm_b32 %1, %1, %6, %7\n\tv_and_b32 %0, %0, %6\n\tv_perm_b32 %2, %2, %6, %7\n\tv_add_u32 %0, %0, %7\n\tv_perm_b32 %3, %3, %6, %7\n\tv_max3_i32 %0, %0, %7, %6\n\tv_perm_b32 %4, %4, %6, %7")
+OPDEP(d_mix2, "v_max3_i32 %0, %0, %6, %7\n\tv_add_u32 %1, %1, %6\n\tv_add_u32 %5, %5, %6\n\tv_and_b32 %0, %0, %6\n\tv_add_u32 %2, %2, %6\n\tv_add_u32 %1, %1, %7\n\tv_add_u32 %0, %0, %7\n\tv_add_u32 %3, %3, %6\n\tv_add_u32 %2, %2, %7\n\tv_max3_i32 %0, %0, %7, %6\n\tv_add_u32 %4, %4, %6\n\tv_add_u32 %3, %3, %7")
+
 typedef void (*kfn)(int*, unsigned long long*, int);
 int main() {
     struct { const char* n; kfn f; int per; } t[] = {
@@ -75,10 +99,14 @@ int main() {
         {"v_max_f32", k_maxf, 1}, {"v_max3_f32", k_max3f, 1}, {"v_max3_i32", k_max3i, 1}, {"v_max_i32", k_maxi, 1}, {"v_max_i16", k_maxi16, 1},
         {"v_max_u16", k_maxu16, 1}, {"v_add_u32", k_add, 1}, {"v_add_i32 clamp", k_addc, 1}, {"v_sub_u32 clamp", k_subc, 1}, {"v_and_b32", k_and, 1},
         {"v_or_b32", k_or, 1}, {"v_xor_b32", k_xor, 1}, {"v_mov_b32", k_mov, 1}, {"v_add_u32_sdwa sext(byte)", k_sdwa, 1}, {"v_perm_b32", k_perm, 1},
-        {"v_pk_max_i16", k_pkmax, 1}, {"v_pk_add_i16", k_pkadd, 1}, {"v_pk_sub_u16 clamp", k_pksubc, 1}, {"v_cndmask_b32 (vcc)", k_cndmask, 1},
+        {"v_pk_max_i16", k_pkmax, 1}, {"v_pk_add_i16", k_pkadd, 1}, {"v_pk_sub_u16 clamp", k_pksubc, 1}, {"v_cndmask_b32 (sgpr mask)", k_cndmask, 1},
         {"v_cmp_eq_u32 + v_mov_b32", k_cmp, 2}, {"v_lshlrev_b32", k_lshl, 1}, {"v_lshl_add_u32", k_lshladd, 1}, {"v_add3_u32", k_add3, 1},
         {"v_mad_i32_i24", k_mad24, 1}, {"v_cvt_f32_ubyte1", k_cvtub, 1}, {"v_mov_b32_dpp wave_shr:1", k_dpp, 1}, {"v_add_u32_dpp row_shr:1", k_adddpp, 1},
         {"s_nop 0", k_nop, 1}};
+    struct { const char* n; kfn f; int chain, total; } dt_[] = {
+        {"v_add_u32 chain", d_add, 4, 4}, {"v_and/v_or chain", d_and, 4, 4}, {"v_max3_i32 chain", d_max3, 4, 4}, {"v_add_u32_sdwa chain", d_sdwa, 4, 4},
+        {"v_mov_b32_dpp wave_shr chain", d_dpp, 4, 4}, {"max3->and->add chain", d_mix, 4, 4}, {"... + 1 v_add filler each", d_mix1, 4, 8},
+        {"... + 1 v_perm filler each", d_mix1s, 4, 8}, {"... + 2 v_add fillers each", d_mix2, 4, 12}};
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int max_blocks = prop.multiProcessorCount * 4 * 8;
@@ -120,6 +148,18 @@ int main() {
         }
         printf("%-28s | %6.2f  %6.2f  %6.2f  %6.2f | %6.2f  %6.2f  %6.2f  %6.2f | %6.2f ms  %5.3f  %5.3f\n", e.n, ct[0], ct[1], ct[2], ct[3], cw[0], cw[1],
                cw[2], cw[3], ms1, ghz[0], ghz[3]);
+    }
+    printf("\nONE wave per SIMD (w = 1), dependent chains: cycles (s_memtime ticks) per CHAIN instruction, and per instruction overall\n");
+    for (auto& e : dt_) {
+        const int blocks = prop.multiProcessorCount * 4;
+        hipLaunchKernelGGL(e.f, dim3(blocks), dim3(64), 0, 0, d, dt, 3);
+        hipDeviceSynchronize();
+        hipMemcpy(ht.data(), dt, (size_t)blocks * 8, hipMemcpyDeviceToHost);
+        double sum = 0;
+        for (int b = 0; b < blocks; ++b) sum += (double)ht[b];
+        const double groups = (double)N_ITER * (UNR / 4);
+        printf("%-32s | %6.2f per chain instruction | %6.2f per instruction (%d of %d on the chain)\n", e.n, sum / blocks / groups / e.chain,
+               sum / blocks / groups / e.total, e.chain, e.total);
     }
     return 0;
 }
