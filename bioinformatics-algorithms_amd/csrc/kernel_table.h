@@ -29,7 +29,8 @@ const BatchKernelEntry* batch_kernel_table(size_t* count);
 const BatchKernelEntry* find_batch_kernel(int R, int mode, int score);
 // pair_kernels.hip
 // perm: coded sequences, table scoring (keyed tb only); keyed = false: the plain int32 traceback form (RL = 4 only)
-pair_kernel_t pair_fill_kernel_for(int rl, int w, bool local, bool tb, bool sband, bool perm, bool keyed = true);
+// gap0: global fill in gap-shifted coordinates (the host passes gap 0 and scores s - 2 gap): perm && keyed && !sband only
+pair_kernel_t pair_fill_kernel_for(int rl, int w, bool local, bool tb, bool sband, bool perm, bool keyed = true, bool gap0 = false);
 pair_kernel_t pair_traceback_kernel_for(int rl, bool local, int walk);   // walk: WALK_NONE / WALK_OPS / WALK_OVERLAP
 
 }  // namespace pwa

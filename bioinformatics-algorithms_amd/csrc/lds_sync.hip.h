@@ -20,4 +20,11 @@ __device__ __forceinline__ void lds_post(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// flag write that only has to stay behind this wave's earlier LDS WRITES: one wave's LDS operations are performed in issue
+// order, so no wait is needed (lds_post's lgkmcnt(0) also waits for read DATA to come back, ~100 cycles per chunk)
+__device__ __forceinline__ void lds_post_after_writes(uint32_t* p, uint32_t v) {
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 }  // namespace pwa

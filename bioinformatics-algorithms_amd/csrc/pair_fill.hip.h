@@ -95,7 +95,8 @@ struct PairDesc {          // one pair of a launch
     uint32_t n_stripes;
     uint32_t row_stride;  // >= m + 64
     uint32_t out_index;   // slot of this pair in PairParams::scores_out
-    uint32_t pad[3];
+    int32_t score_bias;   // global fills in gap-shifted coordinates (G = H - gap (i + j), GAP0 kernels): gap * (n + m), else 0
+    uint32_t pad[2];
 };
 
 struct StripeTask {       // one workgroup task: W consecutive stripes of one pair
@@ -111,6 +112,9 @@ struct PairParams {
     StripeBest* best;       // per stripe (SW)
     int32_t* scores_out;    // optional device score vector in caller order (nullptr: results only in PairResult)
     int32_t match, mismatch, gap;
+    int32_t trace_stripe;         // debugging: stripes trace_stripe .. +3 also record the start time of each of their first 8192 chunks
+    uint32_t trace_base;          //            at stamps[trace_base + 8192 * k + chunk]
+    unsigned long long* stamps;   // debugging (PWA_STAMPS): per stripe {start, first interior chunk, end, -} in s_memrealtime ticks (10 ns), or nullptr
     int32_t dash;           // WALK_OVERLAP: the arena's symbol for a literal '-' (its code when the arena is coded), or a
                             // value no symbol has when no sequence contains one (hw2.cpp:269 skips such columns)
 };
@@ -339,11 +343,16 @@ __device__ __forceinline__ int dpp_fill_shr1(int dst, int v) { return __builtin_
 // -- one compare and RL + 2 selects per step.  (r01 ran those steps through a predicated, rolled loop at ~2.7x the cost of an
 // interior step; as every stripe waits for the first ~80 steps of the stripe above, that ramp was the whole pipeline's
 // start-up lag: 220 interior steps per stripe instead of 80 [gpu, tools/pair_scaling.py].)
-template <int RL, bool LOCAL, bool SBAND, bool PERM, bool GUARD>
+// GAP0 (global, table scoring, no score band): the host runs the fill in gap-shifted coordinates G = H - gap (i + j), i.e. the
+// same recurrence with gap 0 and scores s - 2 gap (ties and codes are unchanged: all three candidates of a cell shift by the same
+// gap (i + j)); with the constants known at compile time the up-candidate IS `base` and the stored value is base | prio(left):
+// 2 instead of 3 instructions behind each v_max3, 2 instead of 3 on the chain.
+template <int RL, bool LOCAL, bool SBAND, bool PERM, bool GUARD, bool GAP0 = false>
 __device__ __forceinline__ void keyed_chunk(const int t0, const int lane, const int m, const int (&pc)[RL], int (&hl)[RL], int& diag0, int& bottom,
                                             int& tch, const int topv, const int tcv, int (&bs)[RL], int (&bj)[RL], const int tab_lo,
                                             const int tab_hi, const int cl, g_u8* tbs, g_i32* sbs, int* ring_out) {
     constexpr int PU = TbCode<LOCAL>::UP, PL = TbCode<LOCAL>::LEFT;
+    static_assert(!GAP0 || (!LOCAL && PERM && !SBAND && PU == 0), "gap-shifted fills: global, table scoring, no score band");
     const int cu = p_addw(cl, PU - PL);
     // band pointers of this lane at step t0: the unrolled steps store at immediate offsets from them
     PWA_GLOBAL uint32_t* const tb4 = (g_u32*)tbs + (size_t)t0 * 64 + lane;
@@ -409,8 +418,8 @@ __device__ __forceinline__ void keyed_chunk(const int t0, const int lane, const 
             chores(3 * r + 1);
             if (SBAND) hsb[r] = k >> 2;
             PWA_SB();
-            up = p_addw(base, cu);                                               // chain: what the row below / the lane below takes
-            hn[r] = p_addw(base, cl);                                            // what the next column (left) and the diagonal take
+            up = GAP0 ? base : p_addw(base, cu);                                 // chain: what the row below / the lane below takes
+            hn[r] = GAP0 ? (base | PL) : p_addw(base, cl);                       // what the next column (left) and the diagonal take
             chores(3 * r + 2);
             if (LOCAL) {
                 if (act && base > bs[r]) {                                       // hw2.cpp:225-229 (bs holds H * 4)
@@ -476,7 +485,7 @@ struct WgShared {
     uint32_t task;
 };
 
-template <int RL, int W, bool LOCAL, bool TB, bool SBAND, bool PERM = false, bool KEYED = true>
+template <int RL, int W, bool LOCAL, bool TB, bool SBAND, bool PERM = false, bool KEYED = true, bool GAP0 = false>
 __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParams G) {
     static_assert(!PERM || (TB && KEYED), "table scoring exists for the keyed (traceback) form only");
     constexpr bool TBK = TB && KEYED;   // values travel as H * 4 + priority
@@ -619,12 +628,19 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
             // round trips between chunks; when the flags were not there yet the chunk start falls back to the polling loop
             int p_topv = 0, p_tcv = 0;
             uint32_t p_ready = 0, p_txt = 0, p_taken = 0;
+            if (G.stamps && lane == 0) G.stamps[(size_t)(P.first_stripe + s) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
             for (int ch = 0; ch < n_chunks; ++ch) {
                 const int t0 = ch * CH;
+                if (G.stamps && lane == 0 && (ch == 1 || ch == 5)) G.stamps[(size_t)(P.first_stripe + s) * 4 + (ch == 1 ? 3 : 1)] = __builtin_amdgcn_s_memrealtime();
+                if (G.stamps && lane == 0 && G.trace_stripe >= 0 && (int)(P.first_stripe + s) >= G.trace_stripe && (int)(P.first_stripe + s) < G.trace_stripe + 4 && ch < 8192)
+                    G.stamps[(size_t)G.trace_base + (size_t)((int)(P.first_stripe + s) - G.trace_stripe) * 8192 + ch] = __builtin_amdgcn_s_memrealtime();
                 // ---- wait for the row above and the text of columns t0 .. t0+CH-1, then take them
                 const uint32_t need = (uint32_t)min(m, t0 + CH);
                 const int c0 = t0 + lane;
                 int topv = 0, tcv = 0;
+                // the look-ahead of the previous chunk when its flags covered this chunk, else the polling loop.  (Tried in r02: re-issuing
+                // the look-ahead reads, one LDS round trip per attempt, instead of the loop -- it narrows the chunk-time distribution
+                // mid-chain (p90 188 -> 156 ticks) but costs the common case more than it gains: C5 13.2 -> 13.4 ms, A/B on one box.)
                 if (TBK && __builtin_amdgcn_readfirstlane(p_ready) >= need && __builtin_amdgcn_readfirstlane(p_txt) >= need) {
                     topv = p_topv;
                     tcv = p_tcv;
@@ -664,13 +680,13 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                     }
                     int* const ring_out = (has_out && lane == 63) ? rout + ring_slot(t0 - 63) : sh.dump[wave] + lane;
                     if (interior)
-                        keyed_chunk<RL, LOCAL, SBAND, PERM, false>(t0, lane, m, pc, hl, diag0, bottom, tch, topv, tcv, bs, bj, a_match, a_mismatch,
+                        keyed_chunk<RL, LOCAL, SBAND, PERM, false, GAP0>(t0, lane, m, pc, hl, diag0, bottom, tch, topv, tcv, bs, bj, a_match, a_mismatch,
                                                                    a_gap, tbs, sbs, ring_out);
                     else
-                        keyed_chunk<RL, LOCAL, SBAND, PERM, true>(t0, lane, m, pc, hl, diag0, bottom, tch, topv, tcv, bs, bj, a_match, a_mismatch,
+                        keyed_chunk<RL, LOCAL, SBAND, PERM, true, GAP0>(t0, lane, m, pc, hl, diag0, bottom, tch, topv, tcv, bs, bj, a_match, a_mismatch,
                                                                   a_gap, tbs, sbs, ring_out);
                     const int hi = min(m, t0 - 63 + CH);
-                    if (has_out && hi > 0) lds_post(&sh.ready[wave + 1], (uint32_t)hi);   // after the chunk's ring writes (one wave: in order)
+                    if (has_out && hi > 0) lds_post_after_writes(&sh.ready[wave + 1], (uint32_t)hi);   // after the chunk's ring writes (one wave: in order)
                     continue;
                 } else if (interior) {
 #pragma unroll PWA_STEP_UNROLL
@@ -701,6 +717,7 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                 }
             }
             if (failed && lane == 0) __hip_atomic_store((g_u32*)(G.queue + 1), 1u, PWA_RLX_AGENT);
+            if (G.stamps && lane == 0) G.stamps[(size_t)(P.first_stripe + s) * 4 + 2] = __builtin_amdgcn_s_memrealtime();
             if (TBK && !LOCAL) {
                 // dp[n][m] (hw2.cpp:186): a lane's state freezes when it leaves the matrix, so the row that holds row n still has
                 // its last column's stored value: H * 4 + gap * 4 + prio(left)
@@ -782,7 +799,11 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
     } else {
         i = P.n;
         j = P.m;
-        if (lane == 0 && G.scores_out) ((g_i32*)G.scores_out)[P.out_index] = res->score;   // written by the fill (hw2.cpp:186)
+        if (lane == 0) {   // dp[n][m], written by the fill (hw2.cpp:186) -- in its own coordinates
+            const int sc = p_addw(res->score, P.score_bias);
+            res->score = sc;
+            if (G.scores_out) ((g_i32*)G.scores_out)[P.out_index] = sc;
+        }
     }
     i = __builtin_amdgcn_readfirstlane(i);
     j = __builtin_amdgcn_readfirstlane(j);

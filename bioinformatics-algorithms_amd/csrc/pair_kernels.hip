@@ -24,7 +24,12 @@ static pair_kernel_t pair_fill_pick_plain_tb(bool local, bool sband) {
     if (local) return sband ? pair_fill_kernel<4, W, true, true, true, false, false> : pair_fill_kernel<4, W, true, true, false, false, false>;
     return sband ? pair_fill_kernel<4, W, false, true, true, false, false> : pair_fill_kernel<4, W, false, true, false, false, false>;
 }
-pair_kernel_t pair_fill_kernel_for(int rl, int w, bool local, bool tb, bool sband, bool perm, bool keyed) {
+pair_kernel_t pair_fill_kernel_for(int rl, int w, bool local, bool tb, bool sband, bool perm, bool keyed, bool gap0) {
+    if (gap0) {   // gap-shifted global fills: table scoring, keyed, no score band
+        if (local || !tb || sband || !perm || !keyed) return nullptr;
+        if (rl == 2) return w == 1 ? pair_fill_kernel<2, 1, false, true, false, true, true, true> : pair_fill_kernel<2, 4, false, true, false, true, true, true>;
+        return w == 1 ? pair_fill_kernel<4, 1, false, true, false, true, true, true> : pair_fill_kernel<4, 4, false, true, false, true, true, true>;
+    }
     if (tb && !keyed) return rl != 4 ? nullptr : (w == 1 ? pair_fill_pick_plain_tb<1>(local, sband) : pair_fill_pick_plain_tb<4>(local, sband));
     if (rl == 2) return w == 1 ? pair_fill_pick<2, 1>(local, tb, sband, perm) : pair_fill_pick<2, 4>(local, tb, sband, perm);
     return w == 1 ? pair_fill_pick<4, 1>(local, tb, sband, perm) : pair_fill_pick<4, 4>(local, tb, sband, perm);

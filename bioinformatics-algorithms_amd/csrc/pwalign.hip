@@ -174,6 +174,8 @@ struct PairGeom {
     int rl, w;
 };
 PairGeom choose_geom(uint64_t max_n, bool keyed = true, bool keyed_tb = false) {
+    // (W = 3 -- three stripes + the helper = one wave per SIMD -- was measured in r02: no gain over W = 4, the stripes behind the
+    // first workgroup run ~5-9 % slower than the first either way: they run at the edge of what their producer has posted.)
     PairGeom g{max_n <= 32768 ? 2 : 4, 4};   // [gpu] 10k x 10k: RL=2 2.27 ms vs RL=4 2.52; 100k x 100k: RL=4 20.9 ms vs RL=2 22.0
     // 129..256 rows: ONE 256-row stripe (W = 1, 8 workgroups per CU) instead of two 128-row stripes in a 4-stripe
     // workgroup with two idle waves; [gpu] 4096 pairs 150 x 10k: fill 8.2 -> 7.3 ms, with the score band 12.1 -> 10.4 ms
@@ -187,8 +189,8 @@ PairGeom choose_geom(uint64_t max_n, bool keyed = true, bool keyed_tb = false) {
     if (const char* e = std::getenv("PWA_FORCE_W")) g.w = std::atoi(e) == 1 ? 1 : 4;
     return g;
 }
-pair_kernel_t pair_fill_fn(PairGeom g, bool local, bool tb, bool sband, bool perm, bool keyed) {
-    return pair_fill_kernel_for(g.rl, g.w, local, tb, sband, perm, keyed);
+pair_kernel_t pair_fill_fn(PairGeom g, bool local, bool tb, bool sband, bool perm, bool keyed, bool gap0) {
+    return pair_fill_kernel_for(g.rl, g.w, local, tb, sband, perm, keyed, gap0);
 }
 pair_kernel_t pair_tb_fn(PairGeom g, bool local, int walk) { return pair_traceback_kernel_for(g.rl, local, walk); }
 
@@ -205,8 +207,11 @@ struct PairLaunch {
     PairGeom geom{4, 4};
     bool perm = false;   // sequences are coded 0..6 (pad 7) and the key constants fit a byte: table-scoring fill kernels
     bool keyed = true;   // traceback fills keep H * 4 + priority (needs |H| < 2^28); false: plain int32 compare-and-select form
+    bool gap0 = false;   // global keyed table-scoring fill in gap-shifted coordinates: build() was given gap 0 and scores s - 2 gap
     uint32_t grid = 0;
     uint64_t row_bytes = 0;
+    uint64_t n_stripes = 0;
+    DevBuf stamps;   // PWA_STAMPS=<file>: per-stripe time stamps of the fill (debugging the stripe pipeline)
 
     // pd[q].{pat,txt,n,m,tb,sband,res,ops,ops_cap} filled by the caller; this adds the pipeline fields
     int build(pwa_ctx* ctx, std::vector<PairDesc>& pd, int match, int mismatch, int gap, PairGeom g) {
@@ -253,6 +258,10 @@ struct PairLaunch {
         G.mismatch = mismatch;
         G.gap = gap;
         G.dash = 0x100;   // no symbol: set by the callers that walk for overlaps
+        G.stamps = nullptr;
+        G.trace_stripe = -1;
+        G.trace_base = 0;
+        n_stripes = n_stripes_total;
         // Tasks come off the queue in global order, so correctness does not depend on how many workgroups
         // are resident.  One workgroup = W compute waves + 1 helper wave.
         grid = (uint32_t)std::min<uint64_t>(tl.size(), (uint64_t)ctx->num_cu * (g.w == 1 ? 8 : 3));
@@ -262,9 +271,22 @@ struct PairLaunch {
     int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, int walk, hipEvent_t after_fill, bool sband = false) {
         HIPC(ctx, hipMemsetAsync(queue.p, 0, 16, st));
         HIPC(ctx, hipMemsetAsync(progress.p, 0, progress.bytes, st));
-        const pair_kernel_t fill = pair_fill_fn(geom, local, tb, sband, perm && tb && keyed, keyed);
+        if (std::getenv("PWA_STAMPS")) {
+            HIPC(ctx, stamps.alloc(n_stripes * 32 + 4 * 8192 * 8));
+            HIPC(ctx, hipMemsetAsync(stamps.p, 0, n_stripes * 32 + 4 * 8192 * 8, st));
+            G.stamps = stamps.as<unsigned long long>();
+            G.trace_base = (uint32_t)(n_stripes * 4);
+            if (const char* e = std::getenv("PWA_TRACE_STRIPE")) G.trace_stripe = std::atoi(e);
+        }
+        const pair_kernel_t fill = pair_fill_fn(geom, local, tb, sband, perm && tb && keyed, keyed, gap0 && tb && keyed && perm && !sband && !local);
         if (!fill) return fail(ctx, PWA_E_INVALID, "internal: no fill kernel for this geometry");
-        hipLaunchKernelGGL(fill, dim3(grid), dim3(64 * (geom.w + 1)), 0, st, G);
+        // A launch with no more multi-stripe workgroups than CUs asks for enough (unused) dynamic LDS that only ONE workgroup
+        // fits a CU: a stripe is one wave alone on its SIMD, and every stripe of a pair moves at the pace of the slowest --
+        // two workgroups sharing a CU's four SIMDs would slow the whole pipeline
+        size_t pad_lds = 0;
+        if (geom.w > 1 && grid <= (uint32_t)ctx->num_cu && !std::getenv("PWA_NO_LDS_PAD")) pad_lds = 96 * 1024;   // static (<= 16 KiB) + 96 KiB > half of the CU's 160 KiB
+        if (pad_lds) HIPC(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds));
+        hipLaunchKernelGGL(fill, dim3(grid), dim3(64 * (geom.w + 1)), pad_lds, st, G);
         HIPC(ctx, hipGetLastError());
         if (after_fill) HIPC(ctx, hipEventRecord(after_fill, st));
         hipLaunchKernelGGL(pair_tb_fn(geom, local, walk), dim3(G.n_pairs), dim3(64), 0, st, G);   // one wave per pair
@@ -273,6 +295,24 @@ struct PairLaunch {
     }
     // after the stream has been synchronised: did a bounded spin give up?
     int check(pwa_ctx* ctx) {
+        if (const char* path = std::getenv("PWA_STAMPS"); path && stamps.p) {
+            std::vector<unsigned long long> h(n_stripes * 4);
+            HIPC(ctx, hipMemcpy(h.data(), stamps.p, n_stripes * 32, hipMemcpyDeviceToHost));
+            if (FILE* f = std::fopen(path, "w")) {
+                for (uint64_t k = 0; k < n_stripes; ++k)
+                    std::fprintf(f, "%llu %llu %llu %llu %llu\n", (unsigned long long)k, h[4 * k] - h[0], h[4 * k + 3] - h[0], h[4 * k + 1] - h[0], h[4 * k + 2] - h[0]);
+                std::fclose(f);
+            }
+            if (G.trace_stripe >= 0) {
+                std::vector<unsigned long long> tr(4 * 8192);
+                HIPC(ctx, hipMemcpy(tr.data(), stamps.as<unsigned long long>() + G.trace_base, tr.size() * 8, hipMemcpyDeviceToHost));
+                if (FILE* f = std::fopen((std::string(path) + ".trace").c_str(), "w")) {
+                    for (int c = 0; c < 8192; ++c)
+                        std::fprintf(f, "%d %llu %llu %llu %llu\n", c, tr[c] - h[0], tr[8192 + c] - h[0], tr[2 * 8192 + c] - h[0], tr[3 * 8192 + c] - h[0]);
+                    std::fclose(f);
+                }
+            }
+        }
         uint32_t q[2] = {0, 0};
         HIPC(ctx, hipMemcpy(q, queue.p, sizeof q, hipMemcpyDeviceToHost));
         if (q[1] != 0) return fail(ctx, PWA_E_HIP, "stripe pipeline timed out waiting for the stripe above");
@@ -1453,6 +1493,17 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     }
     // scores x lengths beyond the packed keys' 2^28: the plain int32 form, exact for anything the reference's int holds
     const bool keyed = tb_range_ok(longest_sum, match, mismatch, gap) && !std::getenv("PWA_NO_KEYED_TB");
+    // Global alignments with table scoring run in gap-shifted coordinates G = H - gap (i + j): the same recurrence with gap 0 and
+    // scores s - 2 gap, identical comparisons and codes, one instruction less per cell (pair_fill.hip.h, GAP0).  |G| <= |H| +
+    // |gap| (n + m): twice the range; both shifted diagonal constants must fit the byte table.
+    bool gap0 = false;
+    if (!local && coded && keyed && !ctx->score_band && !std::getenv("PWA_NO_GAP_SHIFT")) {
+        const int64_t sm = (int64_t)match - 2 * (int64_t)gap, sx = (int64_t)mismatch - 2 * (int64_t)gap;
+        const int64_t km = sm * 4 + 1, kx = sx * 4 + 1;   // (s' - 0) * 4 + prio(diag) - prio(left)
+        const int64_t amax = std::max<int64_t>({std::llabs((long long)match), std::llabs((long long)mismatch), std::llabs((long long)gap), 1});
+        gap0 = km <= 127 && km >= -126 && kx <= 127 && kx >= -126 && (longest_sum + 2) <= (1ull << 27) / (uint64_t)amax;
+    }
+    const int k_match = gap0 ? match - 2 * gap : match, k_mismatch = gap0 ? mismatch - 2 * gap : mismatch, k_gap = gap0 ? 0 : gap;
     const PairGeom geom = choose_geom(longest_n, keyed, true);
     auto tb_band_bytes = [&](uint64_t n, uint64_t m) { return ::tb_band_bytes(n, m, geom.rl); };
     // pairs are processed in chunks whose traceback bands fit the free HBM
@@ -1526,6 +1577,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
                 d.res = d_res.as<PairResult>() + q;
                 d.ops = want_ops ? d_ops.as<uint8_t>() + oo : d_ops.as<uint8_t>();   // WALK_OVERLAP never writes ops
                 d.ops_cap = (uint32_t)std::min<uint64_t>(n + m, 0xffffffffu);
+                d.score_bias = gap0 ? wrap_mul((int64_t)(n + m), gap) : 0;
                 pd.push_back(d);
                 bo += align_up(tb_band_bytes(n, m), 256);
                 ctx->band_bytes += tb_band_bytes(n, m) * (ctx->score_band ? 5 : 1);
@@ -1541,7 +1593,8 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         if (!pd.empty()) {
             pl.perm = coded && keyed;
             pl.keyed = keyed;
-            int rc = pl.build(ctx, pd, match, mismatch, gap, geom);
+            pl.gap0 = gap0;
+            int rc = pl.build(ctx, pd, k_match, k_mismatch, k_gap, geom);
             if (rc != PWA_OK) return rc;
             pl.G.dash = dash_sym;
             mark("task list build + upload");

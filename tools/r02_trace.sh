@@ -1,0 +1,6 @@
+#!/bin/bash
+source tools/gpu_steps.sh
+O=gpurun_out/r02
+mkdir -p $O
+step trace 200 bash -c "PWA_TRACE_STRIPE=${1:-0} PWA_STAMPS=$O/stamps_c5.txt python bench.py --workload c5 --steps 1 --warmup 1 > $O/bench_c5_stamps.json 2> $O/bench_c5_stamps.err"
+ls -la $O/stamps_c5.txt*
