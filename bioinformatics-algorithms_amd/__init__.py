@@ -334,6 +334,31 @@ class Context:
                             start=(startc[2 * k], startc[2 * k + 1])))
         return res
 
+    def align_batch_arrays(self, mode, packed, pair_a, pair_b, match, mismatch, gap, out=None):
+        """pwa_align_batch on caller-held buffers, the way a compiled host calls it: `packed` = pack_sequences(seqs) done once,
+        pair_a / pair_b numpy uint32 arrays, `out` the dict a previous call returned (its arrays are reused, nothing is
+        allocated or converted per call).  Returns dict(scores, n_ops, ops, ops_off, end, start) of numpy arrays; the ops of
+        pair k are ops[ops_off[k] : ops_off[k] + n_ops[k]]."""
+        import numpy as np
+        blob, off, seqs = packed
+        n = len(pair_a)
+        if out is None:
+            lens = np.array([len(x) for x in seqs], dtype=np.uint64)
+            cap = lens[pair_a] + lens[pair_b]
+            ops_off = np.zeros(max(n, 1), dtype=np.uint64)
+            if n > 1:
+                ops_off[1:n] = np.cumsum(cap[:-1])
+            out = dict(scores=np.zeros(max(n, 1), dtype=np.int32), n_ops=np.zeros(max(n, 1), dtype=np.uint64),
+                       ops=np.zeros(int(cap.sum()) + 1, dtype=np.uint8), ops_off=ops_off,
+                       end=np.zeros((max(n, 1), 2), dtype=np.uint64), start=np.zeros((max(n, 1), 2), dtype=np.uint64))
+        u32p, u64p, i32p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
+        rc = self._L.pwa_align_batch(self._h, MODE[mode], match, mismatch, gap, blob, off, len(seqs),
+                                     pair_a.ctypes.data_as(u32p), pair_b.ctypes.data_as(u32p), n, out["scores"].ctypes.data_as(i32p),
+                                     out["ops"].ctypes.data_as(C.c_void_p), out["ops_off"].ctypes.data_as(u64p),
+                                     out["n_ops"].ctypes.data_as(u64p), out["end"].ctypes.data_as(u64p), out["start"].ctypes.data_as(u64p))
+        self._check(rc, "pwa_align_batch")
+        return out
+
     def align_affine_batch(self, seqs, pair_a, pair_b, match, mismatch, gap_open, gap_extend):
         """hw3.cpp:23-135 for a pair list -> [dict(score, ops)], ops in traceback order ('M' / 'D' / 'I')."""
         blob, off, seqs = pack_sequences(seqs)

@@ -42,6 +42,13 @@ struct pwa_ctx {
     // the strip hand-off workspace of the last destroyed batch (5.2 GB for C3): the next batch takes it over
     void* hand_cache = nullptr;
     size_t hand_cache_bytes = 0;
+    // pwa_align* work buffers (sequence arena, op lists, results, pair descriptors, task list, hand-off rows, progress words,
+    // per-stripe bests, queue): grow-only, reused by the next call -- a call that aligns a batch costs no hipMalloc / hipFree
+    // (each of which also synchronises the device) once the context has seen a batch of that size
+    enum { POOL_ARENA, POOL_OPS, POOL_RES, POOL_DESC, POOL_TASKS, POOL_ROWS, POOL_PROGRESS, POOL_BEST, POOL_QUEUE, POOL_N };
+    void* pool[POOL_N] = {};
+    size_t pool_bytes[POOL_N] = {};
+    std::vector<uint8_t> host_arena;   // staging of the coded arena (capacity kept between calls)
 };
 constexpr size_t kBandCacheMax = 24ull << 30;
 
@@ -102,9 +109,9 @@ void radix_sort_by_key(std::vector<uint64_t>& key, std::vector<uint32_t>& idx) {
 // 16 host threads (one per >= 8 MiB): the host passes over the input (alphabet scan, symbol coding into the
 // arena) are memory-bound loops that otherwise dominate the call for inputs of hundreds of MB.
 template <class F>
-void for_seq_ranges(const uint64_t* seq_off, uint32_t n_seq, F&& fn, int* n_threads_out = nullptr) {
+void for_seq_ranges(const uint64_t* seq_off, uint32_t n_seq, F&& fn, int* n_threads_out = nullptr, uint64_t bytes_per_thread = 8ull << 20) {
     const uint64_t total = n_seq ? seq_off[n_seq] - seq_off[0] : 0;
-    int T = (int)std::min<uint64_t>({16, total / (8ull << 20) + 1, std::max(1u, std::thread::hardware_concurrency())});
+    int T = (int)std::min<uint64_t>({16, total / bytes_per_thread + 1, std::max(1u, std::thread::hardware_concurrency())});
     T = std::max(1, std::min<int>(T, (int)std::max<uint32_t>(n_seq, 1)));
     if (n_threads_out) *n_threads_out = T;
     std::vector<uint32_t> cut((size_t)T + 1, n_seq);
@@ -203,6 +210,16 @@ size_t tb_band_bytes(uint64_t n, uint64_t m, int rl) {
 // stripe-task list, hand-off rows, progress counters, per-stripe bests.
 struct PairLaunch {
     DevBuf desc, tasks, rows, progress, best, queue;
+    bool from_pool = false;   // take the six buffers from the context's pool (one launch at a time per context: pwa_align*)
+    void *p_desc = nullptr, *p_tasks = nullptr, *p_rows = nullptr, *p_progress = nullptr, *p_best = nullptr, *p_queue = nullptr;
+    size_t progress_bytes = 0;
+    hipError_t take(pwa_ctx* ctx, DevBuf& own, int slot, size_t bytes, void** out) {
+        if (bytes == 0) bytes = 16;
+        if (from_pool) return cached_workspace(ctx->pool[slot], ctx->pool_bytes[slot], bytes, own, out);
+        const hipError_t e = own.alloc(bytes);
+        *out = own.p;
+        return e;
+    }
     PairParams G{};
     PairGeom geom{4, 4};
     bool perm = false;   // sequences are coded 0..6 (pad 7) and the key constants fit a byte: table-scoring fill kernels
@@ -233,27 +250,28 @@ struct PairLaunch {
             n_stripes_total += ns;
         }
         row_bytes = rows_i32 * sizeof(int32_t);
-        HIPC(ctx, rows.alloc(row_bytes));
+        HIPC(ctx, take(ctx, rows, pwa_ctx::POOL_ROWS, row_bytes, &p_rows));
         uint64_t ro = 0;
         for (auto& d : pd) {
-            d.rows = rows.as<int32_t>() + ro;
+            d.rows = static_cast<int32_t*>(p_rows) + ro;
             const uint64_t nsup = ((uint64_t)d.n_stripes + g.w - 1) / g.w;
             ro += (nsup - 1) * d.row_stride;
         }
-        HIPC(ctx, desc.alloc(pd.size() * sizeof(PairDesc)));
-        HIPC(ctx, hipMemcpy(desc.p, pd.data(), pd.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
-        HIPC(ctx, tasks.alloc(tl.size() * sizeof(StripeTask)));
-        HIPC(ctx, hipMemcpy(tasks.p, tl.data(), tl.size() * sizeof(StripeTask), hipMemcpyHostToDevice));
-        HIPC(ctx, progress.alloc(align_up(tl.size() * sizeof(uint32_t), 16)));
-        HIPC(ctx, best.alloc(std::max<uint64_t>(n_stripes_total, 1) * sizeof(StripeBest)));
-        HIPC(ctx, queue.alloc(64));
-        G.pairs = desc.as<PairDesc>();
-        G.tasks = tasks.as<StripeTask>();
+        HIPC(ctx, take(ctx, desc, pwa_ctx::POOL_DESC, pd.size() * sizeof(PairDesc), &p_desc));
+        HIPC(ctx, hipMemcpy(p_desc, pd.data(), pd.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
+        HIPC(ctx, take(ctx, tasks, pwa_ctx::POOL_TASKS, tl.size() * sizeof(StripeTask), &p_tasks));
+        HIPC(ctx, hipMemcpy(p_tasks, tl.data(), tl.size() * sizeof(StripeTask), hipMemcpyHostToDevice));
+        progress_bytes = align_up(tl.size() * sizeof(uint32_t), 16);
+        HIPC(ctx, take(ctx, progress, pwa_ctx::POOL_PROGRESS, progress_bytes, &p_progress));
+        HIPC(ctx, take(ctx, best, pwa_ctx::POOL_BEST, std::max<uint64_t>(n_stripes_total, 1) * sizeof(StripeBest), &p_best));
+        HIPC(ctx, take(ctx, queue, pwa_ctx::POOL_QUEUE, 64, &p_queue));
+        G.pairs = static_cast<PairDesc*>(p_desc);
+        G.tasks = static_cast<StripeTask*>(p_tasks);
         G.n_pairs = (uint32_t)pd.size();
         G.n_tasks = (uint32_t)tl.size();
-        G.queue = queue.as<uint32_t>();
-        G.progress = progress.as<uint32_t>();
-        G.best = best.as<StripeBest>();
+        G.queue = static_cast<uint32_t*>(p_queue);
+        G.progress = static_cast<uint32_t*>(p_progress);
+        G.best = static_cast<StripeBest*>(p_best);
         G.match = match;
         G.mismatch = mismatch;
         G.gap = gap;
@@ -269,8 +287,8 @@ struct PairLaunch {
     }
     // enqueue: zero the queue / progress words, fill, then the walk (or only the end-cell pick)
     int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, int walk, hipEvent_t after_fill, bool sband = false) {
-        HIPC(ctx, hipMemsetAsync(queue.p, 0, 16, st));
-        HIPC(ctx, hipMemsetAsync(progress.p, 0, progress.bytes, st));
+        HIPC(ctx, hipMemsetAsync(p_queue, 0, 16, st));
+        HIPC(ctx, hipMemsetAsync(p_progress, 0, progress_bytes, st));
         if (std::getenv("PWA_STAMPS")) {
             HIPC(ctx, stamps.alloc(n_stripes * 32 + 4 * 8192 * 8));
             HIPC(ctx, hipMemsetAsync(stamps.p, 0, n_stripes * 32 + 4 * 8192 * 8, st));
@@ -314,7 +332,7 @@ struct PairLaunch {
             }
         }
         uint32_t q[2] = {0, 0};
-        HIPC(ctx, hipMemcpy(q, queue.p, sizeof q, hipMemcpyDeviceToHost));
+        HIPC(ctx, hipMemcpy(q, p_queue, sizeof q, hipMemcpyDeviceToHost));
         if (q[1] != 0) return fail(ctx, PWA_E_HIP, "stripe pipeline timed out waiting for the stripe above");
         return PWA_OK;
     }
@@ -405,6 +423,8 @@ void pwa_ctx_destroy(pwa_ctx* c) {
     if (c->band_cache) (void)hipFree(c->band_cache);
     if (c->sband_cache) (void)hipFree(c->sband_cache);
     if (c->hand_cache) (void)hipFree(c->hand_cache);
+    for (void* q : c->pool)
+        if (q) (void)hipFree(q);
     delete c;
 }
 
@@ -1453,9 +1473,17 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     bool dash_seen = false;
     {
         bool seen[256] = {false};
-        for (uint32_t s = 0; s < n_seq; ++s)
-            if (is_used[s])
-                for (uint64_t o = seq_off[s]; o < seq_off[s + 1]; ++o) seen[seq_bytes[o]] = true;
+        {   // one pass over every used byte: on a few threads once the input reaches megabytes
+            bool part[16][256] = {};
+            for_seq_ranges(seq_off, n_seq, [&](uint32_t s0, uint32_t s1, int t) {
+                bool* mine = part[t];
+                for (uint32_t s = s0; s < s1; ++s)
+                    if (is_used[s])
+                        for (uint64_t o = seq_off[s]; o < seq_off[s + 1]; ++o) mine[seq_bytes[o]] = true;
+            }, nullptr, 1ull << 20);
+            for (int t = 0; t < 16; ++t)
+                for (int v = 0; v < 256; ++v) seen[v] |= part[t][v];
+        }
         int n_alpha = 0;
         for (int v = 0; v < 256; ++v) {
             code_of[v] = (uint8_t)std::min(n_alpha, 7);
@@ -1469,21 +1497,26 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     // overlapLongestExactMatch (hw2.cpp:269) does not count a column whose symbols are '-' -- also when the '-' is part
     // of the input sequence itself: the walk needs the arena's value for that byte
     const int32_t dash_sym = !dash_seen ? 0x100 : (coded ? (int32_t)code_of[(unsigned char)'-'] : (int32_t)'-');
-    DevBuf arena;
+    DevBuf arena_own;
+    void* p_arena = nullptr;
     {
-        std::vector<uint8_t> host_arena(arena_bytes, 0);
-        for (uint32_t s = 0; s < n_seq; ++s)
-            if (is_used[s] && slen(s)) {
-                uint8_t* dst = host_arena.data() + aoff[s];
-                const uint8_t* src = seq_bytes + seq_off[s];
-                if (coded)
-                    for (uint64_t o = 0; o < slen(s); ++o) dst[o] = code_of[src[o]];
-                else
-                    std::memcpy(dst, src, slen(s));
-            }
-        HIPC(ctx, arena.alloc(arena_bytes));
-        HIPC(ctx, hipMemcpy(arena.p, host_arena.data(), arena_bytes, hipMemcpyHostToDevice));
+        std::vector<uint8_t>& host_arena = ctx->host_arena;
+        host_arena.assign(arena_bytes, 0);
+        for_seq_ranges(seq_off, n_seq, [&](uint32_t s0, uint32_t s1, int) {
+            for (uint32_t s = s0; s < s1; ++s)
+                if (is_used[s] && slen(s)) {
+                    uint8_t* dst = host_arena.data() + aoff[s];
+                    const uint8_t* src = seq_bytes + seq_off[s];
+                    if (coded)
+                        for (uint64_t o = 0; o < slen(s); ++o) dst[o] = code_of[src[o]];
+                    else
+                        std::memcpy(dst, src, slen(s));
+                }
+        }, nullptr, 1ull << 20);
+        HIPC(ctx, cached_workspace(ctx->pool[pwa_ctx::POOL_ARENA], ctx->pool_bytes[pwa_ctx::POOL_ARENA], arena_bytes, arena_own, &p_arena));
+        HIPC(ctx, hipMemcpy(p_arena, host_arena.data(), arena_bytes, hipMemcpyHostToDevice));
     }
+    uint8_t* const arena_base = static_cast<uint8_t*>(p_arena);
     mark("arena upload");
 
     uint64_t longest_n = 0, longest_sum = 0;
@@ -1518,6 +1551,8 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     const uint64_t chunk_target = std::min<uint64_t>(budget, ctx->score_band ? (10ull << 30) : (6ull << 30));
     struct Chunk {
         uint64_t k0, k1, band, opsb;
+        bool tiled;      // the caller's op regions ops_off[k] .. + n_k + m_k of the chunk's pairs follow one another without a gap:
+        uint64_t span;   // the device op buffer then mirrors that range and comes back with ONE copy, straight into `ops`
     };
     std::vector<Chunk> chunks;
     uint64_t band_cap = 0, ops_cap_b = 0, nc_cap = 0;
@@ -1534,48 +1569,63 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         }
         if (band * (ctx->score_band ? 5 : 1) + opsb > budget && band + opsb > (uint64_t)(free_b * 0.97))
             return fail(ctx, PWA_E_NOMEM, "traceback band of a single pair exceeds free HBM");
-        chunks.push_back({k0, k1, band, opsb});
+        bool tiled = want_ops;
+        uint64_t span = 0;
+        if (want_ops) {
+            for (uint64_t k = k0; k < k1; ++k) {
+                const uint64_t cap = slen(pair_a[k]) + slen(pair_b[k]);
+                if (k + 1 < k1 && ops_off[k + 1] != ops_off[k] + cap) tiled = false;
+                span += cap;
+            }
+            if (std::getenv("PWA_NO_TILED_OPS")) tiled = false;
+        }
+        chunks.push_back({k0, k1, band, opsb, tiled, span});
         band_cap = std::max(band_cap, band);
-        ops_cap_b = std::max(ops_cap_b, opsb);
+        ops_cap_b = std::max(ops_cap_b, std::max(opsb, tiled ? span + 16 : 0));
         nc_cap = std::max(nc_cap, k1 - k0);
         k0 = k1;
     }
-    DevBuf d_band, d_sband, d_ops, d_res;
-    void *p_band = nullptr, *p_sband = nullptr;
+    DevBuf d_band, d_sband, d_ops_own, d_res_own;
+    void *p_band = nullptr, *p_sband = nullptr, *p_ops = nullptr, *p_res = nullptr;
     if (!chunks.empty()) {
         // + one traceback window: the walk stages whole windows
         HIPC(ctx, cached_workspace(ctx->band_cache, ctx->band_cache_bytes, band_cap + 32768, d_band, &p_band));
         if (ctx->score_band)
             HIPC(ctx, cached_workspace(ctx->sband_cache, ctx->sband_cache_bytes, band_cap * sizeof(int32_t), d_sband, &p_sband));
-        HIPC(ctx, d_ops.alloc(want_ops ? ops_cap_b : 16));
-        HIPC(ctx, d_res.alloc(nc_cap * sizeof(PairResult)));
+        HIPC(ctx, cached_workspace(ctx->pool[pwa_ctx::POOL_OPS], ctx->pool_bytes[pwa_ctx::POOL_OPS], want_ops ? ops_cap_b : 16, d_ops_own, &p_ops));
+        HIPC(ctx, cached_workspace(ctx->pool[pwa_ctx::POOL_RES], ctx->pool_bytes[pwa_ctx::POOL_RES], nc_cap * sizeof(PairResult), d_res_own, &p_res));
     }
     mark("band / ops allocation");
-    std::vector<uint8_t> host_ops(want_ops ? ops_cap_b : 0);
+    uint8_t* const d_ops = static_cast<uint8_t*>(p_ops);
+    PairResult* const d_res = static_cast<PairResult*>(p_res);
+    std::vector<uint8_t> host_ops;   // staging, only for chunks whose op regions do not tile
 
     for (const Chunk& ch : chunks) {
         const uint64_t k0 = ch.k0, k1 = ch.k1, band = ch.band, opsb = ch.opsb;
         const uint64_t nc = k1 - k0;
         PairLaunch pl;
+        pl.from_pool = true;
         std::vector<PairResult> res(nc);
         std::vector<PairDesc> pd;
         std::vector<uint64_t> ooff(nc);
         uint64_t bo = 0, oo = 0;
+        const uint64_t ops_lo = (want_ops && nc) ? ops_off[k0] : 0;
+        if (want_ops && !ch.tiled) host_ops.resize(opsb);
         for (uint64_t q = 0; q < nc; ++q) {
             const uint64_t k = k0 + q, n = slen(pair_a[k]), m = slen(pair_b[k]);
             std::memset(&res[q], 0, sizeof(PairResult));
-            ooff[q] = oo;
+            ooff[q] = ch.tiled ? ops_off[k] - ops_lo : oo;
             if (n && m) {
                 PairDesc d;
                 std::memset(&d, 0, sizeof d);
-                d.pat = arena.as<uint8_t>() + aoff[pair_a[k]];
-                d.txt = arena.as<uint8_t>() + aoff[pair_b[k]];
+                d.pat = arena_base + aoff[pair_a[k]];
+                d.txt = arena_base + aoff[pair_b[k]];
                 d.n = (int32_t)n;
                 d.m = (int32_t)m;
                 d.tb = static_cast<uint8_t*>(p_band) + bo;
                 if (ctx->score_band) d.sband = static_cast<int32_t*>(p_sband) + bo;
-                d.res = d_res.as<PairResult>() + q;
-                d.ops = want_ops ? d_ops.as<uint8_t>() + oo : d_ops.as<uint8_t>();   // WALK_OVERLAP never writes ops
+                d.res = d_res + q;
+                d.ops = want_ops ? d_ops + ooff[q] : d_ops;   // WALK_OVERLAP never writes ops
                 d.ops_cap = (uint32_t)std::min<uint64_t>(n + m, 0xffffffffu);
                 d.score_bias = gap0 ? wrap_mul((int64_t)(n + m), gap) : 0;
                 pd.push_back(d);
@@ -1588,7 +1638,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
             }
             oo += align_up(n + m + 1, 16);
         }
-        HIPC(ctx, hipMemcpy(d_res.p, res.data(), nc * sizeof(PairResult), hipMemcpyHostToDevice));
+        HIPC(ctx, hipMemcpy(d_res, res.data(), nc * sizeof(PairResult), hipMemcpyHostToDevice));
         mark("chunk descriptors");
         if (!pd.empty()) {
             pl.perm = coded && keyed;
@@ -1614,8 +1664,9 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
             ctx->fill_ms += a;
             ctx->tb_ms += c;
         }
-        HIPC(ctx, hipMemcpy(res.data(), d_res.p, nc * sizeof(PairResult), hipMemcpyDeviceToHost));
-        if (want_ops) HIPC(ctx, hipMemcpy(host_ops.data(), d_ops.p, opsb, hipMemcpyDeviceToHost));
+        HIPC(ctx, hipMemcpy(res.data(), d_res, nc * sizeof(PairResult), hipMemcpyDeviceToHost));
+        if (want_ops && ch.tiled && ch.span) HIPC(ctx, hipMemcpy(ops + ops_lo, d_ops, ch.span, hipMemcpyDeviceToHost));   // straight into the caller's list
+        if (want_ops && !ch.tiled) HIPC(ctx, hipMemcpy(host_ops.data(), d_ops, opsb, hipMemcpyDeviceToHost));
         mark("results (+ ops) to host");
         for (uint64_t q = 0; q < nc; ++q) {
             const uint64_t k = k0 + q, n = slen(pair_a[k]), m = slen(pair_b[k]);
@@ -1630,7 +1681,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
                 if (overlap_out) overlap_out[k] = 0;
             } else {
                 if (res[q].overflow) return fail(ctx, PWA_E_CAPACITY, "internal: traceback longer than n+m");
-                if (want_ops) std::memcpy(ops + ops_off[k], host_ops.data() + ooff[q], cnt);
+                if (want_ops && !ch.tiled) std::memcpy(ops + ops_off[k], host_ops.data() + ooff[q], cnt);
                 if (start_cells) {
                     start_cells[2 * k] = res[q].start_i;
                     start_cells[2 * k + 1] = res[q].start_j;
