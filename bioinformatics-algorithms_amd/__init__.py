@@ -112,7 +112,9 @@ def _b(x):
 
 
 def pack_sequences(seqs):
-    """list of bytes -> (concatenated bytes, uint64 offsets[n+1])"""
+    """list of bytes -> (concatenated bytes, uint64 offsets[n+1], the list); an already packed triple passes through"""
+    if isinstance(seqs, tuple) and len(seqs) == 3 and isinstance(seqs[0], (bytes, bytearray)):
+        return seqs
     seqs = [_b(s) for s in seqs]
     off = (C.c_uint64 * (len(seqs) + 1))()
     tot = 0

@@ -22,6 +22,35 @@
 
 using namespace pwa;
 
+__global__ void pwa_nop_kernel(int* p) {
+    if (p && threadIdx.x == 12345) *p = 0;
+}
+
+// Host-side source / destination of the library's own host <-> device copies: page-locked, grow-only, kept in the context.
+// hipMemcpy from a short-lived pageable vector works, but the runtime registers its pages with the driver for the DMA, and
+// when the vector is freed the unmap notifier evicts the process's GPU queues: the NEXT kernel submission then takes 14-24 ms
+// [gpu, r02: tools/cold_start.py, PWA_PROBE] -- which is what made the first run of every fresh batch 25 ms late.
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    hipError_t reserve(size_t n) {   // contents are NOT kept
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        n = (n + (n >> 2) + 4095) & ~(size_t)4095;   // 25 % headroom: few regrowths
+        const hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+        if (e == hipSuccess) cap = n;
+        else p = nullptr;
+        return e;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
 // ------------------------------------------------------------------------------------ context
 struct pwa_ctx {
     int device = 0;
@@ -48,7 +77,9 @@ struct pwa_ctx {
     enum { POOL_ARENA, POOL_OPS, POOL_RES, POOL_DESC, POOL_TASKS, POOL_ROWS, POOL_PROGRESS, POOL_BEST, POOL_QUEUE, POOL_N };
     void* pool[POOL_N] = {};
     size_t pool_bytes[POOL_N] = {};
-    std::vector<uint8_t> host_arena;   // staging of the coded arena (capacity kept between calls)
+    // page-locked staging of everything the library itself uploads or reads back (see PinnedBuf)
+    enum { PIN_ARENA, PIN_TASKS, PIN_SLOT0, PIN_SLOT1, PIN_SLOT2, PIN_SLOT3, PIN_SLOT4, PIN_DESC, PIN_TL, PIN_RES, PIN_BOUNCE, PIN_N };
+    PinnedBuf pin[PIN_N];
 };
 constexpr size_t kBandCacheMax = 24ull << 30;
 
@@ -105,6 +136,17 @@ void radix_sort_by_key(std::vector<uint64_t>& key, std::vector<uint32_t>& idx) {
     }
 }
 
+// Stable counting sort of `idx` by key(idx[i]) in [0, n_buckets): two linear passes.
+template <class KeyFn>
+void counting_sort(std::vector<uint32_t>& idx, std::vector<uint32_t>& tmp, size_t n_buckets, KeyFn key) {
+    std::vector<uint32_t> cnt(n_buckets + 1, 0);
+    for (const uint32_t v : idx) ++cnt[key(v) + 1];
+    for (size_t b = 0; b < n_buckets; ++b) cnt[b + 1] += cnt[b];
+    tmp.resize(idx.size());
+    for (const uint32_t v : idx) tmp[cnt[key(v)]++] = v;
+    idx.swap(tmp);
+}
+
 // Runs fn(first_seq, last_seq, thread) over the sequences, split into byte-balanced contiguous ranges, on up to
 // 16 host threads (one per >= 8 MiB): the host passes over the input (alphabet scan, symbol coding into the
 // arena) are memory-bound loops that otherwise dominate the call for inputs of hundreds of MB.
@@ -154,6 +196,18 @@ hipError_t cached_workspace(void*& slot, size_t& slot_bytes, size_t bytes, DevBu
     }
     *out = slot;
     return hipSuccess;
+}
+
+// pageable memory that the library does not own (or that is too large to mirror in page-locked memory): through a bounce buffer
+hipError_t upload_via_bounce(pwa_ctx* c, void* dst, const void* src, size_t bytes) {
+    constexpr size_t kChunk = 8u << 20;
+    hipError_t e = c->pin[pwa_ctx::PIN_BOUNCE].reserve(std::min(bytes, kChunk));
+    for (size_t o = 0; e == hipSuccess && o < bytes; o += kChunk) {
+        const size_t n = std::min(kChunk, bytes - o);
+        std::memcpy(c->pin[pwa_ctx::PIN_BOUNCE].p, static_cast<const uint8_t*>(src) + o, n);
+        e = hipMemcpy(static_cast<uint8_t*>(dst) + o, c->pin[pwa_ctx::PIN_BOUNCE].p, n, hipMemcpyHostToDevice);
+    }
+    return e;
 }
 
 int fail(pwa_ctx* c, int code, const std::string& msg) {
@@ -258,9 +312,13 @@ struct PairLaunch {
             ro += (nsup - 1) * d.row_stride;
         }
         HIPC(ctx, take(ctx, desc, pwa_ctx::POOL_DESC, pd.size() * sizeof(PairDesc), &p_desc));
-        HIPC(ctx, hipMemcpy(p_desc, pd.data(), pd.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
+        HIPC(ctx, ctx->pin[pwa_ctx::PIN_DESC].reserve(pd.size() * sizeof(PairDesc)));
+        std::memcpy(ctx->pin[pwa_ctx::PIN_DESC].p, pd.data(), pd.size() * sizeof(PairDesc));
+        HIPC(ctx, hipMemcpy(p_desc, ctx->pin[pwa_ctx::PIN_DESC].p, pd.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
         HIPC(ctx, take(ctx, tasks, pwa_ctx::POOL_TASKS, tl.size() * sizeof(StripeTask), &p_tasks));
-        HIPC(ctx, hipMemcpy(p_tasks, tl.data(), tl.size() * sizeof(StripeTask), hipMemcpyHostToDevice));
+        HIPC(ctx, ctx->pin[pwa_ctx::PIN_TL].reserve(tl.size() * sizeof(StripeTask)));
+        std::memcpy(ctx->pin[pwa_ctx::PIN_TL].p, tl.data(), tl.size() * sizeof(StripeTask));
+        HIPC(ctx, hipMemcpy(p_tasks, ctx->pin[pwa_ctx::PIN_TL].p, tl.size() * sizeof(StripeTask), hipMemcpyHostToDevice));
         progress_bytes = align_up(tl.size() * sizeof(uint32_t), 16);
         HIPC(ctx, take(ctx, progress, pwa_ctx::POOL_PROGRESS, progress_bytes, &p_progress));
         HIPC(ctx, take(ctx, best, pwa_ctx::POOL_BEST, std::max<uint64_t>(n_stripes_total, 1) * sizeof(StripeBest), &p_best));
@@ -452,8 +510,6 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
     if (n_pairs >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "more than 2^32-2 pairs in one batch");
     for (uint32_t s = 0; s < n_seq; ++s)
         if (seq_off[s + 1] < seq_off[s]) return fail(ctx, PWA_E_INVALID, "seq_off not monotone");
-    for (uint64_t k = 0; k < n_pairs; ++k)
-        if (pair_a[k] >= n_seq || pair_b[k] >= n_seq) return fail(ctx, PWA_E_INVALID, "pair index out of range");
     HIPC(ctx, hipSetDevice(ctx->device));
     const bool dbg = std::getenv("PWA_DEBUG") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -462,6 +518,13 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         const auto now = std::chrono::steady_clock::now();
         std::fprintf(stderr, "[pwa] create: %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
+        if (std::getenv("PWA_PROBE")) {   // how long does a kernel submission take at this point?
+            hipLaunchKernelGGL(pwa_nop_kernel, dim3(1), dim3(64), 0, ctx->stream, (int*)nullptr);
+            (void)hipStreamSynchronize(ctx->stream);
+            const auto t2 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[pwa]     probe after it: nop kernel + sync %8.3f ms\n", std::chrono::duration<double, std::milli>(t2 - now).count());
+            t_last = t2;
+        }
     };
 
     pwa_batch* b = new (std::nothrow) pwa_batch();
@@ -478,44 +541,48 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
 
     auto slen = [&](uint32_t s) -> uint64_t { return seq_off[s + 1] - seq_off[s]; };
 
-    // ---- pairs with an empty side never reach a kernel (hw2.cpp: loops 138/205 do not run)
+    // ---- one pass over the pair list: index check, and pairs with an empty side never reach a kernel (hw2.cpp: loops
+    // 138/205 do not run) -- they are resolved here
     b->host_scores.assign(n_pairs, 0);
     if (b->want_end) {
         b->host_end_i.assign(n_pairs, 0);
         b->host_end_j.assign(n_pairs, 0);
     }
-    std::vector<uint32_t> live;
-    live.reserve(n_pairs);
-    uint64_t max_n = 0, max_m = 0;
+    std::vector<uint32_t> live(n_pairs);
+    uint64_t max_n = 0, max_m = 0, n_live = 0;
+    bool any_trivial_score = false;
     for (uint64_t k = 0; k < n_pairs; ++k) {
+        if (pair_a[k] >= n_seq || pair_b[k] >= n_seq) return fail(ctx, PWA_E_INVALID, "pair index out of range");
         const uint64_t n = slen(pair_a[k]), m = slen(pair_b[k]);
-        if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
         if (n == 0 || m == 0) {
             if (nwdist) {   // hw4.cpp:21-28 + 146-152: an all-gap alignment, every column counts
                 b->host_scores[k] = (int32_t)(n + m);
             } else if (affine) {   // hw3.cpp:39-52: V[0][0] = 0, F[n][0] = Go + Ge(n-1), E[0][m] = Go + Ge(m-1)
                 b->host_scores[k] = (n + m == 0) ? 0 : (int32_t)((uint32_t)gap + (uint32_t)wrap_mul((int64_t)(n + m - 1), gap_extend));
             } else if (!local) b->host_scores[k] = wrap_mul((int64_t)(n + m), gap);   // dp[n][0] / dp[0][m], hw2.cpp:125-136
+            any_trivial_score = any_trivial_score || b->host_scores[k] != 0;
             if (b->want_end && !local) {
                 b->host_end_i[k] = (uint32_t)n;
                 b->host_end_j[k] = (uint32_t)m;
             }
             continue;
         }
-        live.push_back((uint32_t)k);
+        if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
+        live[n_live++] = (uint32_t)k;
         b->cells += n * m;
         max_n = std::max(max_n, n);
         max_m = std::max(max_m, m);
     }
+    live.resize(n_live);
     b->n_live = live.size();
 
     HIPC(ctx, b->scores.alloc(std::max<uint64_t>(n_pairs, 1) * sizeof(int32_t)));
-    HIPC(ctx, hipMemcpy(b->scores.p, b->host_scores.data(), n_pairs * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIPC(ctx, b->queue.alloc(64));
-    for (int e = 0; e < pwa_batch::kRing; ++e) {
-        HIPC(ctx, hipEventCreate(&b->ev0[e]));
-        HIPC(ctx, hipEventCreate(&b->ev1[e]));
+    if (any_trivial_score) HIPC(ctx, upload_via_bounce(ctx, b->scores.p, b->host_scores.data(), n_pairs * sizeof(int32_t)));
+    else {   // (on the context's stream and waited for: a run may be enqueued on any stream afterwards)
+        HIPC(ctx, hipMemsetAsync(b->scores.p, 0, std::max<uint64_t>(n_pairs, 1) * sizeof(int32_t), ctx->stream));
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));
     }
+    HIPC(ctx, b->queue.alloc(64));   // (the event ring of the runs is created run by run: pwa_batch_run)
     if (live.empty()) {
         b->kernel_name = "none";
         guard.b = nullptr;
@@ -644,9 +711,10 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
     arena_bytes += 512;   // slack: strips and text words are over-read, never over-used
     if (arena_bytes >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "sequence arena exceeds 4 GiB");
     {
-        // not value-initialised: the threads below write every sequence byte and zero the gaps themselves
-        std::unique_ptr<uint8_t[]> host_arena_buf(new uint8_t[arena_bytes]);
-        uint8_t* const host_arena = host_arena_buf.get();
+        // page-locked staging kept in the context; not value-initialised: the threads below write every sequence byte and zero
+        // the gaps themselves
+        HIPC(ctx, ctx->pin[pwa_ctx::PIN_ARENA].reserve(arena_bytes));
+        uint8_t* const host_arena = ctx->pin[pwa_ctx::PIN_ARENA].as<uint8_t>();
         const bool coded = b->use_strips && score_path == SC_PERM;
         uint8_t code8[256];
         for (int v = 0; v < 256; ++v) code8[v] = (uint8_t)(code_of[v] >= 0 ? code_of[v] : 7);
@@ -683,10 +751,25 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         // ---- wave tasks: pairs grouped by text, patterns sorted by length, 64 per wave
         std::vector<uint32_t> order(live);   // ascending pair index: the stable sorts below keep it as the last key
         {
-            std::vector<uint64_t> key(order.size());   // text ascending, pattern length descending (lengths < 2^31)
-            for (size_t o = 0; o < order.size(); ++o)
-                key[o] = ((uint64_t)pair_b[order[o]] << 32) | (uint64_t)(0x7fffffffu - (uint32_t)slen(pair_a[order[o]]));
-            radix_sort_by_key(key, order);
+            // text ascending, pattern length descending.  Stable counting sorts, least significant key first: two linear passes
+            // per key, and the length pass is skipped when every pattern has the same length (a million-pair cross product:
+            // ~3 ms [gpu box] against 14 ms for the 64-bit radix sort, which stays as the fallback for huge key ranges)
+            uint64_t lmin = ~0ull, lmax = 0;
+            for (const uint32_t k : order) {
+                const uint64_t l = slen(pair_a[k]);
+                lmin = std::min(lmin, l);
+                lmax = std::max(lmax, l);
+            }
+            if (lmax - lmin < (1u << 22) && n_seq <= (1u << 24)) {
+                std::vector<uint32_t> tmp;
+                if (lmax != lmin) counting_sort(order, tmp, (size_t)(lmax - lmin + 1), [&](uint32_t k) { return (size_t)(lmax - slen(pair_a[k])); });
+                counting_sort(order, tmp, (size_t)n_seq, [&](uint32_t k) { return (size_t)pair_b[k]; });
+            } else {
+                std::vector<uint64_t> key(order.size());   // text ascending, pattern length descending (lengths < 2^31)
+                for (size_t o = 0; o < order.size(); ++o)
+                    key[o] = ((uint64_t)pair_b[order[o]] << 32) | (uint64_t)(0x7fffffffu - (uint32_t)slen(pair_a[order[o]]));
+                radix_sort_by_key(key, order);
+            }
         }
         struct HostTask {
             uint32_t text, first, count;
@@ -787,9 +870,23 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             return x.first < y.first;
         });
         const size_t nt = ht.size();
-        std::vector<BatchTask> tasks(nt);
-        std::vector<uint32_t> spoff(nt * 64, 0), splen(nt * 64, 0), sout(nt * 64, 0xffffffffu);
-        std::vector<uint32_t> stoff(b->lanes ? nt * 64 : 0, 0), stlen(b->lanes ? nt * 64 : 0, 0);   // empty lanes: no text, no pattern
+        // task list and lane slots are built in page-locked buffers of the context and uploaded from there (see PinnedBuf)
+        HIPC(ctx, ctx->pin[pwa_ctx::PIN_TASKS].reserve(nt * sizeof(BatchTask)));
+        for (int q = 0; q < (b->lanes ? 5 : 3); ++q) HIPC(ctx, ctx->pin[pwa_ctx::PIN_SLOT0 + q].reserve(nt * 64 * sizeof(uint32_t)));
+        BatchTask* const tasks = ctx->pin[pwa_ctx::PIN_TASKS].as<BatchTask>();
+        uint32_t* const spoff = ctx->pin[pwa_ctx::PIN_SLOT0].as<uint32_t>();
+        uint32_t* const splen = ctx->pin[pwa_ctx::PIN_SLOT1].as<uint32_t>();
+        uint32_t* const sout = ctx->pin[pwa_ctx::PIN_SLOT2].as<uint32_t>();
+        uint32_t* const stoff = b->lanes ? ctx->pin[pwa_ctx::PIN_SLOT3].as<uint32_t>() : nullptr;   // empty lanes: no text, no pattern
+        uint32_t* const stlen = b->lanes ? ctx->pin[pwa_ctx::PIN_SLOT4].as<uint32_t>() : nullptr;
+        std::memset(tasks, 0, nt * sizeof(BatchTask));
+        std::memset(spoff, 0, nt * 64 * sizeof(uint32_t));
+        std::memset(splen, 0, nt * 64 * sizeof(uint32_t));
+        std::memset(sout, 0xff, nt * 64 * sizeof(uint32_t));
+        if (b->lanes) {
+            std::memset(stoff, 0, nt * 64 * sizeof(uint32_t));
+            std::memset(stlen, 0, nt * 64 * sizeof(uint32_t));
+        }
         uint32_t max_strips = 1;
         size_t two_strip_tasks = 0;
         for (size_t t = 0; t < nt; ++t) {
@@ -834,23 +931,23 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
                 }
             }
             HIPC(ctx, b->lane_text.alloc(total + 64));
-            HIPC(ctx, hipMemcpy(b->lane_text.p, rows.get(), total + 64, hipMemcpyHostToDevice));
+            HIPC(ctx, upload_via_bounce(ctx, b->lane_text.p, rows.get(), total + 64));
         }
         if (b->lanes) {
             HIPC(ctx, b->slot_toff.alloc(nt * 64 * 4));
-            HIPC(ctx, hipMemcpy(b->slot_toff.p, stoff.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+            HIPC(ctx, hipMemcpy(b->slot_toff.p, stoff, nt * 64 * 4, hipMemcpyHostToDevice));
             HIPC(ctx, b->slot_tlen.alloc(nt * 64 * 4));
-            HIPC(ctx, hipMemcpy(b->slot_tlen.p, stlen.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+            HIPC(ctx, hipMemcpy(b->slot_tlen.p, stlen, nt * 64 * 4, hipMemcpyHostToDevice));
         }
         mark("choose R + slot arrays");
         HIPC(ctx, b->tasks.alloc(nt * sizeof(BatchTask)));
-        HIPC(ctx, hipMemcpy(b->tasks.p, tasks.data(), nt * sizeof(BatchTask), hipMemcpyHostToDevice));
+        HIPC(ctx, hipMemcpy(b->tasks.p, tasks, nt * sizeof(BatchTask), hipMemcpyHostToDevice));
         HIPC(ctx, b->slot_poff.alloc(nt * 64 * 4));
-        HIPC(ctx, hipMemcpy(b->slot_poff.p, spoff.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+        HIPC(ctx, hipMemcpy(b->slot_poff.p, spoff, nt * 64 * 4, hipMemcpyHostToDevice));
         HIPC(ctx, b->slot_plen.alloc(nt * 64 * 4));
-        HIPC(ctx, hipMemcpy(b->slot_plen.p, splen.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+        HIPC(ctx, hipMemcpy(b->slot_plen.p, splen, nt * 64 * 4, hipMemcpyHostToDevice));
         HIPC(ctx, b->slot_out.alloc(nt * 64 * 4));
-        HIPC(ctx, hipMemcpy(b->slot_out.p, sout.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+        HIPC(ctx, hipMemcpy(b->slot_out.p, sout, nt * 64 * 4, hipMemcpyHostToDevice));
 
         b->single_strip = !affine && !nwdist && max_strips == 1 && b->kern->fn_single != nullptr;
         // Opt-in (PWA_PAIRED=1): two-strip tasks (the C3 shape: 150-row patterns in 76-row strips) as two waves of one
@@ -957,6 +1054,17 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         }
         b->kernel_name = std::string("pair_fill_kernel<RL=") + std::to_string(geom.rl) + (local ? ",SW" : ",NW") + ",no-traceback>";
     }
+    if (dbg) {
+        mark("engine setup");
+        HIPC(ctx, hipDeviceSynchronize());
+        mark("hipDeviceSynchronize");
+        hipLaunchKernelGGL(pwa_nop_kernel, dim3(1), dim3(64), 0, ctx->stream, (int*)nullptr);
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));
+        mark("nop kernel + sync");
+        hipLaunchKernelGGL(pwa_nop_kernel, dim3(1), dim3(64), 0, ctx->stream, (int*)nullptr);
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));
+        mark("nop kernel + sync again");
+    }
     guard.b = nullptr;
     *out = b;
     return PWA_OK;
@@ -1055,7 +1163,7 @@ int pwa_align_affine_batch(pwa_ctx* ctx, int match, int mismatch, int gap_open, 
         for (uint32_t s = 0; s < n_seq; ++s)
             if (is_used[s] && slen(s)) std::memcpy(host_arena.data() + aoff[s], seq_bytes + seq_off[s], slen(s));
         HIPC(ctx, arena.alloc(arena_bytes));
-        HIPC(ctx, hipMemcpy(arena.p, host_arena.data(), arena_bytes, hipMemcpyHostToDevice));
+        HIPC(ctx, upload_via_bounce(ctx, arena.p, host_arena.data(), arena_bytes));
     }
 
     // ---- wave tasks: pairs grouped by string1, string2 sorted by length (descending), 64 per wave
@@ -1129,17 +1237,17 @@ int pwa_align_affine_batch(pwa_ctx* ctx, int match, int mismatch, int gap_open, 
         DevBuf d_tb, d_tasks, d_spoff, d_splen, d_sout, d_tboff, d_wp;
         HIPC(ctx, d_tb.alloc(dw * 4));
         HIPC(ctx, d_tasks.alloc(nt * sizeof(BatchTask)));
-        HIPC(ctx, hipMemcpy(d_tasks.p, tasks.data(), nt * sizeof(BatchTask), hipMemcpyHostToDevice));
+        HIPC(ctx, upload_via_bounce(ctx, d_tasks.p, tasks.data(), nt * sizeof(BatchTask)));
         HIPC(ctx, d_spoff.alloc(nt * 64 * 4));
-        HIPC(ctx, hipMemcpy(d_spoff.p, spoff.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+        HIPC(ctx, upload_via_bounce(ctx, d_spoff.p, spoff.data(), nt * 64 * 4));
         HIPC(ctx, d_splen.alloc(nt * 64 * 4));
-        HIPC(ctx, hipMemcpy(d_splen.p, splen.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+        HIPC(ctx, upload_via_bounce(ctx, d_splen.p, splen.data(), nt * 64 * 4));
         HIPC(ctx, d_sout.alloc(nt * 64 * 4));
-        HIPC(ctx, hipMemcpy(d_sout.p, sout.data(), nt * 64 * 4, hipMemcpyHostToDevice));
+        HIPC(ctx, upload_via_bounce(ctx, d_sout.p, sout.data(), nt * 64 * 4));
         HIPC(ctx, d_tboff.alloc(nt * sizeof(uint64_t)));
-        HIPC(ctx, hipMemcpy(d_tboff.p, tboff.data(), nt * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIPC(ctx, upload_via_bounce(ctx, d_tboff.p, tboff.data(), nt * sizeof(uint64_t)));
         HIPC(ctx, d_wp.alloc(wp.size() * sizeof(AffineWalkPair)));
-        HIPC(ctx, hipMemcpy(d_wp.p, wp.data(), wp.size() * sizeof(AffineWalkPair), hipMemcpyHostToDevice));
+        HIPC(ctx, upload_via_bounce(ctx, d_wp.p, wp.data(), wp.size() * sizeof(AffineWalkPair)));
 
         AffineTbParams T;
         std::memset(&T, 0, sizeof T);
@@ -1200,6 +1308,10 @@ int pwa_batch_run(pwa_batch* b, void* stream_v) {
     HIPC(ctx, hipSetDevice(ctx->device));   // the caller's thread may have another device current
     hipStream_t st = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
     const int slot = (int)(b->n_runs % pwa_batch::kRing);
+    if (!b->ev0[slot]) {
+        HIPC(ctx, hipEventCreate(&b->ev0[slot]));
+        HIPC(ctx, hipEventCreate(&b->ev1[slot]));
+    }
     HIPC(ctx, hipEventRecord(b->ev0[slot], st));
     if (b->n_live) {
         if (b->use_strips) {
@@ -1500,12 +1612,13 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     DevBuf arena_own;
     void* p_arena = nullptr;
     {
-        std::vector<uint8_t>& host_arena = ctx->host_arena;
-        host_arena.assign(arena_bytes, 0);
+        HIPC(ctx, ctx->pin[pwa_ctx::PIN_ARENA].reserve(arena_bytes));
+        uint8_t* const host_arena = ctx->pin[pwa_ctx::PIN_ARENA].as<uint8_t>();
+        std::memset(host_arena, 0, arena_bytes);
         for_seq_ranges(seq_off, n_seq, [&](uint32_t s0, uint32_t s1, int) {
             for (uint32_t s = s0; s < s1; ++s)
                 if (is_used[s] && slen(s)) {
-                    uint8_t* dst = host_arena.data() + aoff[s];
+                    uint8_t* dst = host_arena + aoff[s];
                     const uint8_t* src = seq_bytes + seq_off[s];
                     if (coded)
                         for (uint64_t o = 0; o < slen(s); ++o) dst[o] = code_of[src[o]];
@@ -1514,7 +1627,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
                 }
         }, nullptr, 1ull << 20);
         HIPC(ctx, cached_workspace(ctx->pool[pwa_ctx::POOL_ARENA], ctx->pool_bytes[pwa_ctx::POOL_ARENA], arena_bytes, arena_own, &p_arena));
-        HIPC(ctx, hipMemcpy(p_arena, host_arena.data(), arena_bytes, hipMemcpyHostToDevice));
+        HIPC(ctx, hipMemcpy(p_arena, host_arena, arena_bytes, hipMemcpyHostToDevice));
     }
     uint8_t* const arena_base = static_cast<uint8_t*>(p_arena);
     mark("arena upload");
@@ -1605,7 +1718,8 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         const uint64_t nc = k1 - k0;
         PairLaunch pl;
         pl.from_pool = true;
-        std::vector<PairResult> res(nc);
+        HIPC(ctx, ctx->pin[pwa_ctx::PIN_RES].reserve(nc * sizeof(PairResult)));
+        PairResult* const res = ctx->pin[pwa_ctx::PIN_RES].as<PairResult>();   // page-locked: uploaded, and read back after the walk
         std::vector<PairDesc> pd;
         std::vector<uint64_t> ooff(nc);
         uint64_t bo = 0, oo = 0;
@@ -1638,7 +1752,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
             }
             oo += align_up(n + m + 1, 16);
         }
-        HIPC(ctx, hipMemcpy(d_res, res.data(), nc * sizeof(PairResult), hipMemcpyHostToDevice));
+        HIPC(ctx, hipMemcpy(d_res, res, nc * sizeof(PairResult), hipMemcpyHostToDevice));
         mark("chunk descriptors");
         if (!pd.empty()) {
             pl.perm = coded && keyed;
@@ -1664,7 +1778,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
             ctx->fill_ms += a;
             ctx->tb_ms += c;
         }
-        HIPC(ctx, hipMemcpy(res.data(), d_res, nc * sizeof(PairResult), hipMemcpyDeviceToHost));
+        HIPC(ctx, hipMemcpy(res, d_res, nc * sizeof(PairResult), hipMemcpyDeviceToHost));
         if (want_ops && ch.tiled && ch.span) HIPC(ctx, hipMemcpy(ops + ops_lo, d_ops, ch.span, hipMemcpyDeviceToHost));   // straight into the caller's list
         if (want_ops && !ch.tiled) HIPC(ctx, hipMemcpy(host_ops.data(), d_ops, opsb, hipMemcpyDeviceToHost));
         mark("results (+ ops) to host");
