@@ -78,7 +78,9 @@ struct pwa_ctx {
     void* pool[POOL_N] = {};
     size_t pool_bytes[POOL_N] = {};
     // page-locked staging of everything the library itself uploads or reads back (see PinnedBuf)
-    enum { PIN_ARENA, PIN_TASKS, PIN_SLOT0, PIN_SLOT1, PIN_SLOT2, PIN_SLOT3, PIN_SLOT4, PIN_DESC, PIN_TL, PIN_RES, PIN_BOUNCE, PIN_N };
+    hipStream_t copy_stream = nullptr;                 // uploads that overlap host work (build_arena)
+    hipEvent_t copy_ev[2] = {nullptr, nullptr};
+    enum { PIN_ARENA, PIN_ARENA2, PIN_TASKS, PIN_SLOT0, PIN_SLOT1, PIN_SLOT2, PIN_SLOT3, PIN_SLOT4, PIN_DESC, PIN_TL, PIN_RES, PIN_BOUNCE, PIN_N };
     PinnedBuf pin[PIN_N];
 };
 constexpr size_t kBandCacheMax = 24ull << 30;
@@ -208,6 +210,64 @@ hipError_t upload_via_bounce(pwa_ctx* c, void* dst, const void* src, size_t byte
         e = hipMemcpy(static_cast<uint8_t*>(dst) + o, c->pin[pwa_ctx::PIN_BOUNCE].p, n, hipMemcpyHostToDevice);
     }
     return e;
+}
+
+// The device arena of a call: every used sequence s at aoff[s] (16-byte aligned) as symbols -- through `table` (256 entries) or
+// copied when table == nullptr -- and zeros everywhere else.  It goes up in pieces of ~32 MiB: while piece k is on its way
+// (copy stream, from one of two page-locked buffers of the context) piece k + 1 is being coded by several host threads into the
+// other -- readFasta's blob is never repacked into a second host copy, and a 570 MB arena costs 2 x 32 MiB of pinned memory.
+hipError_t build_arena(pwa_ctx* c, void* d_arena, uint64_t arena_bytes, const uint8_t* seq_bytes, const uint64_t* seq_off, uint32_t n_seq,
+                       const std::vector<uint8_t>& is_used, const std::vector<uint64_t>& aoff, const uint8_t* table) {
+    constexpr uint64_t kPiece = 32ull << 20;
+    std::vector<uint32_t> used;
+    for (uint32_t s = 0; s < n_seq; ++s)
+        if (is_used[s]) used.push_back(s);
+    if (used.empty()) return hipMemset(d_arena, 0, arena_bytes);
+    hipError_t e = hipSuccess;
+    int piece = 0;
+    for (size_t u0 = 0; u0 < used.size() && e == hipSuccess; ++piece) {
+        size_t u1 = u0 + 1;
+        const uint64_t a0 = u0 == 0 ? 0 : aoff[used[u0]];
+        auto end_of = [&](size_t u) { return u < used.size() ? aoff[used[u]] : arena_bytes; };
+        while (u1 < used.size() && end_of(u1 + 1) - a0 <= kPiece) ++u1;
+        const uint64_t a1 = end_of(u1), bytes = a1 - a0;
+        PinnedBuf& pb = c->pin[pwa_ctx::PIN_ARENA + (piece & 1)];
+        if (piece >= 2) e = hipEventSynchronize(c->copy_ev[piece & 1]);   // the copy that last read this buffer
+        if (e == hipSuccess) e = pb.reserve(bytes);
+        if (e != hipSuccess) break;
+        uint8_t* const host = pb.as<uint8_t>();
+        // sequences u0 .. u1-1 of the piece over a few threads, byte-balanced
+        const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>({16, bytes / (1ull << 20) + 1, std::max(1u, std::thread::hardware_concurrency()), (uint64_t)(u1 - u0)}));
+        auto work = [&](int t) {
+            const uint64_t lo = a0 + bytes / T * t, hi = t + 1 == T ? a1 : a0 + bytes / T * (t + 1);
+            // first sequence whose region starts at or after lo (regions are [aoff[s], aoff[next]))
+            size_t u = std::lower_bound(used.begin() + u0, used.begin() + u1, lo, [&](uint32_t sidx, uint64_t v) { return aoff[sidx] < v; }) - used.begin();
+            if (t == 0) {
+                u = u0;
+                if (a0 < aoff[used[u0]]) std::memset(host, 0, aoff[used[u0]] - a0);
+            }
+            for (; u < u1 && aoff[used[u]] < hi; ++u) {
+                const uint32_t sidx = used[u];
+                const uint64_t len = seq_off[sidx + 1] - seq_off[sidx], r0 = aoff[sidx], r1 = end_of(u + 1);
+                uint8_t* dst = host + (r0 - a0);
+                const uint8_t* src = seq_bytes + seq_off[sidx];
+                if (table)
+                    for (uint64_t o = 0; o < len; ++o) dst[o] = table[src[o]];
+                else if (len)
+                    std::memcpy(dst, src, len);
+                std::memset(dst + len, 0, r1 - r0 - len);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+        e = hipMemcpyAsync(static_cast<uint8_t*>(d_arena) + a0, host, bytes, hipMemcpyHostToDevice, c->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(c->copy_ev[piece & 1], c->copy_stream);
+        u0 = u1;
+    }
+    const hipError_t e2 = hipStreamSynchronize(c->copy_stream);
+    return e != hipSuccess ? e : e2;
 }
 
 int fail(pwa_ctx* c, int code, const std::string& msg) {
@@ -468,6 +528,11 @@ int pwa_ctx_create(int device, pwa_ctx** out) {
             pwa_ctx_destroy(c);
             return PWA_E_HIP;
         }
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->copy_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->copy_ev[1], hipEventDisableTiming) != hipSuccess) {
+        pwa_ctx_destroy(c);
+        return PWA_E_HIP;
+    }
     *out = c;
     return PWA_OK;
 }
@@ -478,6 +543,9 @@ void pwa_ctx_destroy(pwa_ctx* c) {
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (auto& e : c->copy_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->band_cache) (void)hipFree(c->band_cache);
     if (c->sband_cache) (void)hipFree(c->sband_cache);
     if (c->hand_cache) (void)hipFree(c->hand_cache);
@@ -711,39 +779,11 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
     arena_bytes += 512;   // slack: strips and text words are over-read, never over-used
     if (arena_bytes >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "sequence arena exceeds 4 GiB");
     {
-        // page-locked staging kept in the context; not value-initialised: the threads below write every sequence byte and zero
-        // the gaps themselves
-        HIPC(ctx, ctx->pin[pwa_ctx::PIN_ARENA].reserve(arena_bytes));
-        uint8_t* const host_arena = ctx->pin[pwa_ctx::PIN_ARENA].as<uint8_t>();
         const bool coded = b->use_strips && score_path == SC_PERM;
         uint8_t code8[256];
         for (int v = 0; v < 256; ++v) code8[v] = (uint8_t)(code_of[v] >= 0 ? code_of[v] : 7);
-        std::vector<uint64_t> aend(n_seq, 0);   // end of the arena region (sequence + zeroed slack) of each used sequence
-        {
-            uint64_t prev_used = n_seq;
-            for (uint32_t s = n_seq; s-- > 0;)
-                if (is_used[s]) {
-                    aend[s] = prev_used < n_seq ? aoff[prev_used] : arena_bytes;
-                    prev_used = s;
-                }
-            if (prev_used < n_seq && aoff[prev_used] > 0) std::memset(host_arena, 0, aoff[prev_used]);
-            if (prev_used == n_seq) std::memset(host_arena, 0, arena_bytes);
-        }
-        for_seq_ranges(seq_off, n_seq, [&](uint32_t s0, uint32_t s1, int) {
-            for (uint32_t s = s0; s < s1; ++s)
-                if (is_used[s]) {
-                    uint8_t* dst = host_arena + aoff[s];
-                    const uint8_t* src = seq_bytes + seq_off[s];
-                    const uint64_t len = slen(s);
-                    if (coded)
-                        for (uint64_t o = 0; o < len; ++o) dst[o] = code8[src[o]];
-                    else
-                        std::memcpy(dst, src, len);
-                    std::memset(dst + len, 0, aend[s] - aoff[s] - len);
-                }
-        });
         HIPC(ctx, b->arena.alloc(arena_bytes));
-        HIPC(ctx, hipMemcpy(b->arena.p, host_arena, arena_bytes, hipMemcpyHostToDevice));
+        HIPC(ctx, build_arena(ctx, b->arena.p, arena_bytes, seq_bytes, seq_off, n_seq, is_used, aoff, coded ? code8 : nullptr));
     }
 
     mark("validate + arena upload");
@@ -1612,22 +1652,8 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     DevBuf arena_own;
     void* p_arena = nullptr;
     {
-        HIPC(ctx, ctx->pin[pwa_ctx::PIN_ARENA].reserve(arena_bytes));
-        uint8_t* const host_arena = ctx->pin[pwa_ctx::PIN_ARENA].as<uint8_t>();
-        std::memset(host_arena, 0, arena_bytes);
-        for_seq_ranges(seq_off, n_seq, [&](uint32_t s0, uint32_t s1, int) {
-            for (uint32_t s = s0; s < s1; ++s)
-                if (is_used[s] && slen(s)) {
-                    uint8_t* dst = host_arena + aoff[s];
-                    const uint8_t* src = seq_bytes + seq_off[s];
-                    if (coded)
-                        for (uint64_t o = 0; o < slen(s); ++o) dst[o] = code_of[src[o]];
-                    else
-                        std::memcpy(dst, src, slen(s));
-                }
-        }, nullptr, 1ull << 20);
         HIPC(ctx, cached_workspace(ctx->pool[pwa_ctx::POOL_ARENA], ctx->pool_bytes[pwa_ctx::POOL_ARENA], arena_bytes, arena_own, &p_arena));
-        HIPC(ctx, hipMemcpy(p_arena, host_arena, arena_bytes, hipMemcpyHostToDevice));
+        HIPC(ctx, build_arena(ctx, p_arena, arena_bytes, seq_bytes, seq_off, n_seq, is_used, aoff, coded ? code_of : nullptr));
     }
     uint8_t* const arena_base = static_cast<uint8_t*>(p_arena);
     mark("arena upload");
