@@ -105,6 +105,19 @@ class DevPtr:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
+def attach_traffic(roofline, workload):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic_<workload>.json, written by
+    tools/make_traffic.py from the rocprofv3 summaries), corrected as MI355X_MICROARCH.md prescribes."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        roofline["traffic"] = tj.get("hbm_bytes_per_launch")
+        roofline["traffic_source"] = tj.get("source")
+        if tj.get("kernel_avg_ms") is not None:
+            roofline["traffic_note"] = "per dispatch of %s (rocprof avg %.4f ms per dispatch)" % (tj.get("kernel"), tj["kernel_avg_ms"])
+
+
 # ----------------------------------------------------------------------------- CPU baseline leg
 def _cpu_one(mode, O, kind, p, t, scoring):
     if mode == "affine":
@@ -114,7 +127,7 @@ def _cpu_one(mode, O, kind, p, t, scoring):
     return (O.ref_align(mode, p, t, *scoring) if kind == "reference" else O.align(mode, p, t, *scoring))["score"]
 
 
-def cpu_baseline(mode, pairs, seqs, scoring, budget_s=20.0, max_pairs=1024):
+def cpu_baseline(mode, pairs, seqs, scoring, budget_s=25.0, max_pairs=2048):
     """Time the unmodified reference (oracle/_ref, kind "reference") or the C restatement (kind
     "port") on a bounded sample of the same workload (`pairs`: a seeded random sample drawn over the WHOLE pair
     list, so that every pattern and text can be hit), 1 thread; then all host cores."""
@@ -337,7 +350,9 @@ def main():
     if use_dist:
         import torch   # noqa: F811
         import torch.distributed as dist   # noqa: F811
-        os.environ["NCCL_DEBUG"] = os.environ.get("BENCH_NCCL_DEBUG", "WARN")   # keep RCCL's banner off stdout: ONE JSON line
+        # ONE JSON line on stdout: RCCL's own messages (banner at INFO, "NCCL WARN Could not read node" on some boxes) go to stderr
+        os.environ["NCCL_DEBUG"] = os.environ.get("BENCH_NCCL_DEBUG", "WARN")
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         if "RANK" not in os.environ:   # BENCH_FORCE_DIST=1 without a launcher: a one-rank group on this process
             import socket
             sk = socket.socket()
@@ -355,7 +370,7 @@ def main():
         dev = torch.tensor([-1 if cpu else torch.cuda.current_device()], dtype=torch.int32, device="cpu" if cpu else "cuda")
         devs = [torch.empty_like(dev) for _ in range(dist.get_world_size())]
         dist.all_gather(devs, dev)
-        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "launcher": "bench.py --gpus N (child processes)" if os.environ.get("BENCH_SELF_LAUNCHED") else "external (torch.distributed.run)",
+        dist_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "launcher": "bench.py --gpus N (child processes)" if os.environ.get("BENCH_SELF_LAUNCHED") else ("single process (BENCH_FORCE_DIST)" if "TORCHELASTIC_RUN_ID" not in os.environ and world == 1 else "external (torch.distributed.run)"),
                      "device_of_rank": [int(d.item()) for d in devs]}
 
     pkg = ctx = None
@@ -525,12 +540,8 @@ def main():
                 "note": "scores-only pass is not HBM-bound; the notional figure prices the int32 score band "
                         "as if it were written (north-star accounting), it is NOT traffic"},
     }
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-    if os.path.exists(tpath) and not (args.workload == "c3i" and mode == "nw"):
-        with open(tpath) as f:
-            tj = json.load(f)
-        roofline["traffic"] = tj.get("hbm_bytes_per_launch")
-        roofline["traffic_source"] = tj.get("source")
+    if not (args.workload == "c3i" and mode == "nw"):
+        attach_traffic(roofline, args.workload)
 
     line = {
         "metric": "GCUPS (billion DP cells/s) SW linear-gap, 1/2/4/8xMI355X; bit-exact vs hw2.cpp"
@@ -563,9 +574,9 @@ def main():
             line["invalid"] = "checksum of rank 0's scores is %d, expected %d" % (line["checksum"], want_sum)
 
     if world == 1 and not args.no_cpu_baseline and not cpu:
-        # verification + CPU baseline on the SAME sample: >= 1024 pairs drawn over the whole pair list (all patterns, all texts)
+        # verification + CPU baseline on the SAME sample: 2048 pairs drawn over the whole pair list (all patterns, all texts), ~13 s of CPU
         rs = np.random.RandomState(481)
-        pick = np.sort(rs.choice(n_pairs, size=min(n_pairs, 1024), replace=False))
+        pick = np.sort(rs.choice(n_pairs, size=min(n_pairs, 2048), replace=False))
         pairs = list(zip(pa[pick].tolist(), pb[pick].tolist()))
         base, ref_scores = cpu_baseline(mode, pairs, seqs, scoring)
         line["cpu_baseline"] = base
@@ -645,13 +656,15 @@ def bench_global_batch(args, pkg, ctx):
         "config": {"workload": ("gb: %d pairs %d x 10000, SW fill writing int32 score band + traceback band (5 B/cell) + walk"
                                 if bands else "g: %d pairs %d x 10000, NW fill + traceback band + walk, host buffers in and ops out") % (n_pairs, plen),
                    "scoring": [1, -1, -1]},
-        "roofline": {"bound": "hbm", "kernel": "pair_fill_kernel<RL=2,%s,TB%s>" % (mode.upper(), ",SBAND" if bands else ""), "achieved": st["band_bytes"] / (k_ms * 1e-3) / 1e9,
+        "roofline": {"bound": "hbm", "kernel": "pair_fill_kernel<RL=4,W=1,%s,TB%s,PERM%s>" % (mode.upper(), ",SBAND" if bands else "", "" if bands else ",GAP0"),
+                     "launches_per_step": "the batch runs as chunks of <= 6 GiB (10 GiB with the score band) of band: achieved / kernel_ms are sums over the step's fill launches", "achieved": st["band_bytes"] / (k_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st["band_bytes"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": None, "algorithmic_bytes_per_launch": st["band_bytes"], "kernel_ms": k_ms,
                      "traceback_ms": float(np.mean(tb)), "kernel_gcups": cells / (k_ms * 1e-3) / 1e9},
         "result": {"score_sum": int(sum(r["score"] for r in res)), "ops_total": int(sum(len(r["ops"]) for r in res))},
         "verified_vs_cpu": {"pairs": int(min(n_pairs, 24)), "what": "score and op list against the CPU oracle", "bit_exact": bool(verified)},
     }
+    attach_traffic(line["roofline"], args.workload)
     if not verified:
         line["invalid"] = "GPU alignments differ from the CPU oracle"
     if args.small:
@@ -701,13 +714,14 @@ def bench_single_pair(args, pkg, ctx, rank, world, dist, torch):
         "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": label + " (replicas only: a single pair does not shard)", "scoring": [1, -1, -1],
                    "includes": "H2D of the pair, fill, traceback walk, D2H of the ops"},
-        "roofline": {"bound": "hbm", "kernel": "pair_fill_kernel<RL=4,%s,TB>" % mode.upper(),
+        "roofline": {"bound": "hbm", "kernel": ("pair_fill_kernel<RL=2,W=4,SW,TB,PERM>" if mode == "sw" else "pair_fill_kernel<RL=4,W=4,NW,TB,PERM,GAP0>"),
                      "achieved": band / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": band / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": band, "kernel_ms": k_ms, "traceback_ms": float(np.mean(tb)),
                      "kernel_gcups": cells / (k_ms * 1e-3) / 1e9},
         "result": {"score": r["score"], "n_ops": len(r["ops"])},
     }
+    attach_traffic(line["roofline"], args.workload)
     if args.small:
         line["invalid"] = "reduced sizes (--small): functional check only"
     print(json.dumps(line), flush=True)

@@ -14,7 +14,9 @@
  *     parameter name starts with d_ (then it is a DEVICE pointer on the context's GPU);
  *   - sequences are RAW BYTES compared for equality (hw2.cpp:142, 208): any alphabet, case-sensitive;
  *   - scores are int32 with the reference's recurrences and tie-breaks; results are bit-identical
- *     to hw2.cpp wherever hw2.cpp itself does not overflow int;
+ *     to hw2.cpp wherever hw2.cpp itself does not overflow int -- for ANY match / mismatch / gap: the fills with a
+ *     traceback band keep H*4+priority keys while max|score| * (n + m + 2) <= 2^28 and switch to a plain int32
+ *     compare-and-select form beyond that (slower, never refused);
  *   - every function returns PWA_OK (0) or a negative PWA_E_* code; nothing throws, exits or
  *     prints across the ABI; pwa_last_error() gives the text of the last failure on a context;
  *   - a context is bound to ONE GPU and is not thread-safe: one context per host thread.
@@ -68,6 +70,10 @@ int pwa_ctx_set_score_band(pwa_ctx *ctx, int on);
  *   score_out[k]      : NW: dp[n][m] (hw2.cpp:186);  SW: max cell (hw2.cpp:225-229)
  *   end_i_out/end_j_out (each may be NULL): the cell the reference's traceback starts from --
  *                       NW (n, m); SW the FIRST maximum in row-major order, (0,0) if all zero.
+ * Pair lists of any size: a batch object addresses its sequence arena with 32-bit offsets (4 GiB of distinct sequences),
+ * so this call (like pwa_distances and pwa_scores_affine) cuts the list into runs of consecutive pairs whose sequences
+ * fit one arena and processes them one after the other.  Remaining limits: a sequence < 2^31 - 64 symbols; pattern +
+ * reference of ONE pair < 4 GiB; < 2^32 - 1 pairs per call.
  */
 int pwa_scores(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const uint8_t *seq_bytes,
                const uint64_t *seq_off, uint32_t n_seq, const uint32_t *pair_a, const uint32_t *pair_b,
@@ -77,7 +83,8 @@ int pwa_scores(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const u
  * The same pass split into prepare / run / fetch so that a caller can keep inputs resident in
  * HBM, time the kernels alone, and hand the device-side score vector to a collective
  * (RCCL all-gather over xGMI) without a host round trip.
- *   pwa_batch_create  uploads the sequences, builds the wave-task list (host), allocates outputs;
+ *   pwa_batch_create  uploads the sequences, builds the wave-task list (host), allocates outputs; PWA_E_CAPACITY when the
+ *                     sequences the pair list uses exceed one 4 GiB arena (split the list, or call pwa_scores);
  *   pwa_batch_run     enqueues the kernels on `stream` (a hipStream_t, NULL = the context's own
  *                     stream) -- asynchronous, no host synchronisation, graph-capturable;
  *   pwa_batch_d_scores  device pointer to int32[n_pairs] in pair order (valid until destroy),
@@ -191,7 +198,10 @@ int pwa_align_last_stats(const pwa_ctx *ctx, float *fill_ms, float *traceback_ms
 /*
  * Full alignment of many pairs (the -g path needs every pair's alignment: hw2.cpp:344).
  * ops of pair k are written at ops[ops_off[k] .. ops_off[k] + n_ops[k]); the caller sizes
- * ops_off so that pair k has room for n_k + m_k bytes.
+ * ops_off so that pair k has room for n_k + m_k bytes.  When the regions follow one another without a gap
+ * (ops_off[k + 1] == ops_off[k] + n_k + m_k) the device op buffer mirrors the caller's and every chunk of pairs comes
+ * back with one copy straight into `ops`; any other layout works through a staging copy.  No sequence-arena limit here
+ * (64-bit device pointers); the traceback bands are processed in chunks that fit the free HBM.
  */
 int pwa_align_batch(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const uint8_t *seq_bytes,
                     const uint64_t *seq_off, uint32_t n_seq, const uint32_t *pair_a, const uint32_t *pair_b,

@@ -540,6 +540,37 @@ def test_cli_sharded_over_devices_matches_oracle_cli(pkg, tmp_path):
     assert rc == 2 and b"no usable gfx950 device" in err or b"failed" in err
 
 
+def test_batches_driven_from_other_threads(pkg):
+    """every batch entry point sets its context's device itself, so a batch may be run / fetched on a thread other
+    than the one that created it, and two contexts may be driven from two threads at once (one GPU here: both on device 0)."""
+    import threading
+    rng = random.Random(21)
+    seqs = [bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 200))) for _ in range(30)]
+    pa = [rng.randrange(30) for _ in range(200)]
+    pb = [rng.randrange(30) for _ in range(200)]
+    want = [O.score("sw", seqs[a], seqs[b], 1, -1, -1)[0] for a, b in zip(pa, pb)]
+    c1, c2 = pkg.Context(0), pkg.Context(0)
+    b1 = c1.batch("sw", seqs, pa, pb, 1, -1, -1)
+    out = {}
+
+    def other(name, batch):
+        batch.run()
+        out[name] = (batch.fetch(), batch.last_ms() > 0)
+
+    def whole(name, c):
+        out[name] = c.scores("sw", seqs, pa, pb, 1, -1, -1)
+
+    th = [threading.Thread(target=other, args=("t1", b1)), threading.Thread(target=whole, args=("t2", c2))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert out["t1"] == (want, True) and out["t2"] == want
+    b1.close()
+    c1.close()
+    c2.close()
+
+
 def test_device_score_vector_in_caller_memory(ctx):
     """pwa_batch_set_d_scores: kernels write into a torch tensor (what bench.py hands to the RCCL all-gather);
     both engines, including pairs with an empty side."""
