@@ -525,10 +525,17 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
             g_u32* prog_out = (g_u32*)(G.progress + tid);
             int kin = 0, kout = 0;
             uint32_t idle = 0;
+            const bool traced = G.stamps && G.trace_stripe >= 0 && (int)(P.first_stripe + ss * W) == G.trace_stripe;   // debugging
+            uint32_t trip = 0;
             for (;;) {
                 const bool done_in = kin >= m, done_out = !bot_global || kout >= m;
                 if (done_in && done_out) break;
                 bool progress = false;
+                if (traced && lane == 0 && trip < 8192) {   // slots 2 / 3 of the trace: time and columns staged / published so far
+                    G.stamps[(size_t)G.trace_base + 2 * 8192 + trip] = __builtin_amdgcn_s_memrealtime();
+                    G.stamps[(size_t)G.trace_base + 3 * 8192 + trip] = ((unsigned long long)(unsigned)kin << 32) | (unsigned)kout;
+                }
+                ++trip;
                 if (!done_in) {   // ---- stage text + the row above wave 0, up to kTrip columns per trip
                     int lim = min(m, min((int)lds_peek(&sh.taken[0]) + kRing, (int)lds_peek(&sh.taken[wl]) + kTRing));
                     if (top_global) lim = min(lim, (int)__hip_atomic_load(prog_in, PWA_RLX_AGENT));   // sc1 poll
@@ -632,7 +639,7 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
             for (int ch = 0; ch < n_chunks; ++ch) {
                 const int t0 = ch * CH;
                 if (G.stamps && lane == 0 && (ch == 1 || ch == 5)) G.stamps[(size_t)(P.first_stripe + s) * 4 + (ch == 1 ? 3 : 1)] = __builtin_amdgcn_s_memrealtime();
-                if (G.stamps && lane == 0 && G.trace_stripe >= 0 && (int)(P.first_stripe + s) >= G.trace_stripe && (int)(P.first_stripe + s) < G.trace_stripe + 4 && ch < 8192)
+                if (G.stamps && lane == 0 && G.trace_stripe >= 0 && (int)(P.first_stripe + s) >= G.trace_stripe && (int)(P.first_stripe + s) < G.trace_stripe + 2 && ch < 8192)
                     G.stamps[(size_t)G.trace_base + (size_t)((int)(P.first_stripe + s) - G.trace_stripe) * 8192 + ch] = __builtin_amdgcn_s_memrealtime();
                 // ---- wait for the row above and the text of columns t0 .. t0+CH-1, then take them
                 const uint32_t need = (uint32_t)min(m, t0 + CH);
