@@ -815,6 +815,42 @@ def test_one_shot_calls_cut_oversized_pair_lists_into_arena_chunks(ctx, monkeypa
     assert ctx.scores_affine_oneshot(seqs, pa, pb, 5, -4, -16, -4) == whole_a == [O.affine_score(seqs[a], seqs[b], 5, -4, -16, -4) for a, b in zip(pa, pb)]
 
 
+@pytest.mark.parametrize("n_class", [(1, 63, 64), (65, 127, 128), (129, 200, 256), (257, 300, 511, 512, 513), (700, 1025, 1100, 1537)])
+def test_pair_engine_shapes_around_every_boundary(ctx, n_class, monkeypatch):
+    """The written-out fill chunks (r02): pattern lengths around stripe / workgroup boundaries x text lengths around hand-off chunks
+    (16 steps), the lane ramp (63 steps) and the LDS ring (512 columns), for both modes, table and compare scoring, gap-shifted and
+    plain global form, with and without the score band -- every op list, end and start cell against the oracle.  All pairs of one
+    n-class go through ONE batch so that they share a geometry (RL, W) and run concurrently."""
+    rng = random.Random(hash(n_class) & 0xffff)
+    ms = [1, 2, 15, 16, 17, 31, 47, 48, 49, 62, 63, 64, 65, 79, 80, 81, 95, 127, 128, 129, 191, 255, 256, 257, 511, 512, 513, 520, 1030]
+    seqs, pa, pb = [], [], []
+    for n in n_class:
+        for m in ms:
+            p = bytes(rng.choice(b"ACGT") for _ in range(n))
+            t = _mutate(rng, (p * (m // max(n, 1) + 2))[:m + 20], 0.1)[:m] if rng.random() < 0.5 else bytes(rng.choice(b"ACGT") for _ in range(m))
+            t = (t + bytes(rng.choice(b"ACGT") for _ in range(m)))[:m]
+            seqs += [p, t]
+            pa.append(len(seqs) - 2)
+            pb.append(len(seqs) - 1)
+    variants = [({}, False), ({"PWA_NO_GAP_SHIFT": "1"}, False), ({"PWA_NO_PAIR_TABLE": "1"}, False), ({}, True)]
+    for env, band in variants:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx.set_score_band(band)
+        try:
+            for mode in ("nw", "sw"):
+                for sc in [(1, -1, -1), (2, -3, -5)]:
+                    res = ctx.align_batch(mode, seqs, pa, pb, *sc)
+                    for k, r in enumerate(res):
+                        want = O.align(mode, seqs[pa[k]], seqs[pb[k]], *sc, compact=True)
+                        assert (r["score"], r["ops"], tuple(r["end"]), tuple(r["start"])) == \
+                            (want["score"], want["ops"], tuple(want["end"]), tuple(want["start"])), (env, band, mode, sc, len(seqs[pa[k]]), len(seqs[pb[k]]))
+        finally:
+            ctx.set_score_band(False)
+            for k in env:
+                monkeypatch.delenv(k, raising=False)
+
+
 def test_pipeline_handoff_under_uneven_concurrent_load(ctx):
     """Many multi-super-stripe pairs of very different shapes in ONE launch: every inter-workgroup hand-off
     (helper wave, sc1 rows + progress counters) runs while other workgroups stream bands at different rates.
