@@ -722,6 +722,35 @@ def bench_single_pair(args, pkg, ctx, rank, world, dist, torch):
         "result": {"score": r["score"], "n_ops": len(r["ops"])},
     }
     attach_traffic(line["roofline"], args.workload)
+    if not args.small:
+        # the alignment itself against what the UNMODIFIED reference produced for this very pair (tests/golden/kat.json: C2,
+        # kat_c5.json: C5 -- one 50 GB run of hw2.cpp): score, CIGAR and MD:Z by sha256, after the timed region
+        import hashlib
+        fmt = pkg.format_alignment(p, t, r["ops"], r["end"])
+        gold = None
+        for name in ("kat_c5.json", "kat.json"):
+            with open(os.path.join(ROOT, "tests", "golden", name)) as f:
+                for rec in json.load(f):
+                    if rec["mode"] == mode and rec["gen_p"] == [1, 0, 0, n] and rec["gen_t"] == [1, 1, 0, m] and rec["scoring"] == [1, -1, -1]:
+                        gold = rec
+        if gold is not None:
+            ok = (r["score"] == gold["score"] and hashlib.sha256(fmt["cigar"]).hexdigest() == gold["cigar_sha256"]
+                  and hashlib.sha256(fmt["mdz"]).hexdigest() == gold["mdz_sha256"] and fmt["overlap"] == gold["overlap"])
+            line["verified_vs_reference"] = {"what": "score, overlap, sha256 of CIGAR and MD:Z of the unmodified hw2.cpp for this pair (committed fixture)",
+                                             "cigar_chars": len(fmt["cigar"]), "bit_exact": bool(ok)}
+            if not ok:
+                line["invalid"] = "the alignment differs from the reference's"
+        if args.workload in ("c2", "c2b") and not args.no_cpu_baseline and rank == 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            kind = "reference" if O.have_ref() else "port"
+            t1 = time.perf_counter()
+            w = (O.ref_align if kind == "reference" else O.align)(mode, p, t, 1, -1, -1)
+            dt = time.perf_counter() - t1
+            line["cpu_baseline"] = {"value": cells / dt / 1e9, "unit": "GCUPS", "cores": 1, "kind": kind,
+                                    "sample": "this pair in full (%.2f s), int + char matrices as hw2.cpp, g++ -O2" % dt}
+            if w["score"] != r["score"] or w["cigar"] != fmt["cigar"]:
+                line["invalid"] = "GPU alignment differs from the CPU baseline"
     if args.small:
         line["invalid"] = "reduced sizes (--small): functional check only"
     print(json.dumps(line), flush=True)
