@@ -10,6 +10,7 @@
 //   hipcc --offload-arch=gfx950 -O2 -o tools/valu_issue tools/valu_issue.hip && tools/valu_issue
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 #define N_ITER 60000
 #define UNR 32
@@ -66,6 +67,46 @@ OP(k_mad24, "v_mad_i32_i24 %0, %1, %2, %3")
 OP(k_cvtub, "v_cvt_f32_ubyte1 %0, %1")
 OP(k_dpp, "v_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf")
 OP(k_adddpp, "v_add_u32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf")
+OP(k_max3i16, "v_max3_i16 %0, %1, %2, %3")
+OP(k_max3u16, "v_max3_u16 %0, %1, %2, %3")
+OP(k_min3i16, "v_min3_i16 %0, %1, %2, %3")
+OP(k_med3i16, "v_med3_i16 %0, %1, %2, %3")
+OP(k_addu16, "v_add_u16 %0, %1, %2")
+OP(k_subu16c, "v_sub_u16_e64 %0, %1, %2 clamp")
+OP(k_addi16c, "v_add_i16 %0, %1, %2 clamp")
+OP(k_madu16, "v_mad_u16 %0, %1, %2, %3")
+OP(k_max3f16, "v_max3_f16 %0, %1, %2, %3")
+OP(k_maxf16, "v_max_f16 %0, %1, %2")
+OP(k_addu16sdwa, "v_add_u16_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
+OP(k_addcou32, "v_addc_co_u32 %0, vcc, %1, %2, vcc")
+OP(k_subrev, "v_subrev_u32 %0, %1, %2")
+OP(k_bfi2, "v_bfi_b32 %0, %1, %2, %3")
+OP(k_andor, "v_and_or_b32 %0, %1, %2, %3")
+// VGPR index mode (the profile form of the batched kernels): 4 indexed full-rate adds between one s_set_gpr_idx_on / _off pair,
+// and the VALU of four SW cells (4 adds + 6 max3 + 4 sub-clamp) with the pair and one s_bfe -- against the table form's
+// (4 sdwa adds + xor + perm + the same).  Counted per CELL.  (Scalar temporaries are compiler-allocated operands, m0 is declared.)
+#define BODY_X(txt)                                                                                                    \
+    int a[8];                                                                                                          \
+    for (int i = 0; i < 8; ++i) a[i] = threadIdx.x * 3 + i + seed;                                                     \
+    int st = seed;                                                                                                     \
+    unsigned long long t0, t1;                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");               \
+    for (int it = 0; it < N_ITER; ++it) {                                                                              \
+        _Pragma("unroll") for (int u = 0; u < UNR / 4; ++u) {                                                          \
+            const int i = u & 7;                                                                                       \
+            asm volatile(txt : "=&v"(a[i]), "+s"(st) : "v"(a[(i + 3) & 7]), "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]) : "m0", "scc"); \
+        }                                                                                                              \
+    }                                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");               \
+    int r = st;                                                                                                        \
+    for (int i = 0; i < 8; ++i) r += a[i];                                                                             \
+    out[blockIdx.x * 64 + threadIdx.x] = r;                                                                            \
+    if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+#define OPX(name, txt) \
+    __global__ __launch_bounds__(64) void name(int* out, unsigned long long* ticks, int seed) { BODY_X(txt) }
+OPX(k_idx4, "s_set_gpr_idx_on 0, 1\n\tv_add_u32 %0, %2, %3\n\tv_add_u32 %0, %2, %4\n\tv_add_u32 %0, %3, %4\n\tv_add_u32 %0, %4, %3\n\ts_set_gpr_idx_off")
+OPX(k_cell4, "s_bfe_u32 %1, %1, 0x80008\n\ts_set_gpr_idx_on 0, 1\n\tv_add_u32 %0, %2, %3\n\tv_add_u32 %0, %2, %4\n\tv_add_u32 %0, %3, %4\n\tv_add_u32 %0, %4, %3\n\ts_set_gpr_idx_off\n\tv_max3_i32 %0, %2, %3, %4\n\tv_sub_u32_e64 %0, %2, %3 clamp\n\tv_max3_i32 %0, %2, %3, %4\n\tv_sub_u32_e64 %0, %2, %4 clamp\n\tv_max3_i32 %0, %4, %3, %2\n\tv_sub_u32_e64 %0, %3, %2 clamp\n\tv_max3_i32 %0, %2, %4, %3\n\tv_sub_u32_e64 %0, %4, %2 clamp\n\tv_max3_i32 %0, %3, %4, %2\n\tv_max3_i32 %0, %3, %2, %4")
+OPX(k_cell4old, "v_add_u32_sdwa %0, %2, sext(%3) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\tv_add_u32_sdwa %0, %2, sext(%4) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\tv_add_u32_sdwa %0, %3, sext(%4) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\tv_add_u32_sdwa %0, %4, sext(%3) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\tv_xor_b32 %0, %2, %3\n\tv_perm_b32 %0, %2, %3, %4\n\tv_max3_i32 %0, %2, %3, %4\n\tv_sub_u32_e64 %0, %2, %3 clamp\n\tv_max3_i32 %0, %2, %3, %4\n\tv_sub_u32_e64 %0, %2, %4 clamp\n\tv_max3_i32 %0, %4, %3, %2\n\tv_sub_u32_e64 %0, %3, %2 clamp\n\tv_max3_i32 %0, %2, %4, %3\n\tv_sub_u32_e64 %0, %4, %2 clamp\n\tv_max3_i32 %0, %3, %4, %2\n\tv_max3_i32 %0, %3, %2, %4")
 OP(k_nop, "s_nop 0")
 
 // dependent chains (every instruction reads the result of the one before it) and chains diluted with independent fillers:
@@ -93,7 +134,8 @@ OPDEP(d_mix1s, "v_max3_i32 %0, %0, %6, %7\n\tv_perm_b32 %1, %1, %6, %7\n\tv_and_
 OPDEP(d_mix2, "v_max3_i32 %0, %0, %6, %7\n\tv_add_u32 %1, %1, %6\n\tv_add_u32 %5, %5, %6\n\tv_and_b32 %0, %0, %6\n\tv_add_u32 %2, %2, %6\n\tv_add_u32 %1, %1, %7\n\tv_add_u32 %0, %0, %7\n\tv_add_u32 %3, %3, %6\n\tv_add_u32 %2, %2, %7\n\tv_max3_i32 %0, %0, %7, %6\n\tv_add_u32 %4, %4, %6\n\tv_add_u32 %3, %3, %7")
 
 typedef void (*kfn)(int*, unsigned long long*, int);
-int main() {
+int main(int argc, char** argv) {
+    const char* only = argc > 1 ? argv[1] : nullptr;   // run only the rows whose name contains this
     struct { const char* n; kfn f; int per; } t[] = {
         {"v_fma_f32", k_fma, 1}, {"v_pk_fma_f32", k_pkfma, 1}, {"v_pk_add_f32", k_pkadd32, 1}, {"v_mul_f32", k_mulf, 1}, {"v_add_f32", k_addf, 1},
         {"v_max_f32", k_maxf, 1}, {"v_max3_f32", k_max3f, 1}, {"v_max3_i32", k_max3i, 1}, {"v_max_i32", k_maxi, 1}, {"v_max_i16", k_maxi16, 1},
@@ -102,7 +144,11 @@ int main() {
         {"v_pk_max_i16", k_pkmax, 1}, {"v_pk_add_i16", k_pkadd, 1}, {"v_pk_sub_u16 clamp", k_pksubc, 1}, {"v_cndmask_b32 (sgpr mask)", k_cndmask, 1},
         {"v_cmp_eq_u32 + v_mov_b32", k_cmp, 2}, {"v_lshlrev_b32", k_lshl, 1}, {"v_lshl_add_u32", k_lshladd, 1}, {"v_add3_u32", k_add3, 1},
         {"v_mad_i32_i24", k_mad24, 1}, {"v_cvt_f32_ubyte1", k_cvtub, 1}, {"v_mov_b32_dpp wave_shr:1", k_dpp, 1}, {"v_add_u32_dpp row_shr:1", k_adddpp, 1},
-        {"s_nop 0", k_nop, 1}};
+        {"v_max3_i16", k_max3i16, 1}, {"v_max3_u16", k_max3u16, 1}, {"v_min3_i16", k_min3i16, 1}, {"v_med3_i16", k_med3i16, 1}, {"v_add_u16", k_addu16, 1},
+        {"v_sub_u16 clamp", k_subu16c, 1}, {"v_add_i16 clamp", k_addi16c, 1}, {"v_mad_u16", k_madu16, 1}, {"v_max3_f16", k_max3f16, 1}, {"v_max_f16", k_maxf16, 1},
+        {"v_add_u16_sdwa sext(byte)", k_addu16sdwa, 1}, {"v_addc_co_u32", k_addcou32, 1}, {"v_subrev_u32", k_subrev, 1}, {"v_bfi_b32", k_bfi2, 1},
+        {"v_and_or_b32", k_andor, 1}, {"idx_on+4 v_add+idx_off /add", k_idx4, 1},
+        {"SW cell, profile form /cell", k_cell4, 1}, {"SW cell, table form   /cell", k_cell4old, 1}, {"s_nop 0", k_nop, 1}};
     struct { const char* n; kfn f; int chain, total; } dt_[] = {
         {"v_add_u32 chain", d_add, 4, 4}, {"v_and/v_or chain", d_and, 4, 4}, {"v_max3_i32 chain", d_max3, 4, 4}, {"v_add_u32_sdwa chain", d_sdwa, 4, 4},
         {"v_mov_b32_dpp wave_shr chain", d_dpp, 4, 4}, {"max3->and->add chain", d_mix, 4, 4}, {"... + 1 v_add filler each", d_mix1, 4, 8},
@@ -124,6 +170,7 @@ int main() {
            "  clock they imply (GHz = ticks / wall).  %d x %d instructions per wave and launch.\n", N_ITER, UNR);
     printf("%-28s | %-31s | %-31s | %s\n", "instruction", "cyc/SIMD (s_memtime ticks)", "cyc/SIMD (wall at 2.4 GHz)", "ms per launch (w=1), tick rate GHz (w=1, w=8)");
     for (auto& e : t) {
+        if (only && !strstr(e.n, only)) continue;
         double ct[4], cw[4], ghz[4], ms1 = 0;
         int q = 0;
         for (int wps : {1, 2, 4, 8}) {
@@ -146,11 +193,13 @@ int main() {
             if (wps == 1) ms1 = ms;
             ++q;
         }
+        fflush(stdout);
         printf("%-28s | %6.2f  %6.2f  %6.2f  %6.2f | %6.2f  %6.2f  %6.2f  %6.2f | %6.2f ms  %5.3f  %5.3f\n", e.n, ct[0], ct[1], ct[2], ct[3], cw[0], cw[1],
                cw[2], cw[3], ms1, ghz[0], ghz[3]);
     }
     printf("\nONE wave per SIMD (w = 1), dependent chains: cycles (s_memtime ticks) per CHAIN instruction, and per instruction overall\n");
     for (auto& e : dt_) {
+        if (only) break;
         const int blocks = prop.multiProcessorCount * 4;
         hipLaunchKernelGGL(e.f, dim3(blocks), dim3(64), 0, 0, d, dt, 3);
         hipDeviceSynchronize();
