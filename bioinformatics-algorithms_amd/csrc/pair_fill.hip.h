@@ -777,7 +777,7 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
     constexpr int WIN = 64;                        // steps per LDS window
     constexpr int STEP_BYTES = 64 * RL;
     constexpr int WB = WIN * STEP_BYTES;           // bytes per window (16 KiB for RL = 4)
-    __shared__ __attribute__((aligned(16))) uint8_t win[WALK != WALK_NONE ? 2 * WB : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t win[WALK != WALK_NONE ? 2 * WB + 16 : 16];   // + a byte that reads "no code"
     const int lane = threadIdx.x;
     const uint32_t pid = blockIdx.x;
     if (pid >= G.n_pairs) return;
@@ -841,8 +841,217 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
     int run = 0, best_run = 0;   // wave-uniform
     uint32_t cnt = 0;
     int cb = 0, cur_s = -1, cur_w = -1, pre_s = -1, pre_w = -1;
-    bool stopped = false;
-    while (i > 0 && j > 0) {
+    bool stopped = false, walk_fault = false;
+    if constexpr (OPS) {
+        // ---- the op-list walk (r02).  Per trip the lanes look at 2A+1 = SEVEN diagonals of the band in one LDS round trip: lane d
+        // reads
+        //   view a = 0:       (i-d, j-d)        the diagonal through the anchor (i, j),
+        //   view a = -1..-A:  (i+a-d, j-d)      the ones the path is on after |a| net 'u',
+        //   view a = +1..+A:  (i-d, j-a-d)      ... after a net 'l',
+        // each view becomes three ballot masks (d / u / l) and a vector of op bytes, and the walk then hops between the views on
+        // SCALAR bit tests alone, written out by hand (hipcc turns the state machine into a loop over state flags, ~32
+        // instructions per hop).  On view a the walk stands on lane p: the run of 'd' codes from p on ends at lane q; lanes
+        // p .. q (q included when it holds 'u' / 'l') store their op bytes to ops[cnt ..] (hw2.cpp:164-179 / 240-255) under
+        // exec = s_bfm(count, p); 'u' moves to view a-1 (same lane while a <= 0, else lane q+1), 'l' to view a+1 (same lane
+        // while a >= 0, else lane q+1); anything else -- a cell outside the staged diagonals, the staged windows or the matrix, a
+        // local alignment's zero cell, lane 63 -- ends the trip there.  18 instructions per hop against ~140 per trip.
+        // A lone wave issues one instruction per ~5.4 cycles whatever its kind, so the walk is priced in instructions per op:
+        // the one-diagonal loop below (kept for the overlap walk) spends ~70 per trip = per non-diagonal op, 206 cycles per op
+        // on C5.  [gpu] C5 walk (116 001 ops): 9.9 ms one diagonal (32 k trips); three views, hipcc's hop code 6.7 ms; hand-written
+        // hops 5.2 ms (16 k trips); five views 4.8 ms (8.2 k); both windows readable 7.5 k trips; seven views 4.6 ms (5.8 k);
+        // nine views 4.7 ms (4.8 k trips, but 100 SGPRs and a longer set-up).  Timing-only builds: hops without their store
+        // and exec writes -0.4 ms, no waits for the prefetched window -0.0 ms: what is left is the instruction count.
+        constexpr int SH = RL == 4 ? 8 : RL == 2 ? 7 : 6, RSH = RL == 4 ? 2 : RL == 2 ? 1 : 0, SR = 64 * RL;
+        static_assert(SR == (1 << SH), "stripe rows");
+        constexpr uint32_t OPTAB = LOCAL ? ((uint32_t)'I' | (uint32_t)'D' << 8 | (uint32_t)'M' << 16)    // local: l 0, u 1, d 2
+                                         : ((uint32_t)'D' | (uint32_t)'I' << 8 | (uint32_t)'M' << 16);   // global: u 0, l 1, d 2
+        constexpr int NOCODE = 2 * WB;
+#ifndef PWA_WALK_A
+#define PWA_WALK_A 3
+#endif
+        constexpr int A = PWA_WALK_A, NV = 2 * A + 1;   // views -A .. +A
+        if (lane == 0) win[NOCODE] = 0xff;
+        const int dl = lane == 63 ? 0x40000000 : lane;   // lane 63 never holds a cell: every run of set mask bits ends by bit 63
+        typedef unsigned long long u64;
+        // The two LDS buffers form a ring over the band steps of a stripe: window w (steps 64 w .. 64 w + 63) lives in buffer
+        // w & 1, so a cell at step t sits at ((t & 127) * 64 + k) * RL + r whichever window it belongs to.  The walk only moves
+        // backwards: next to the window of the anchor the one before it is in flight from the moment the walk enters, and once it
+        // has landed (checked a few trips later: s_waitcnt also waits for the op stores still on their way) the lanes may read
+        // both -- a trip then reaches as far as its 63 lanes and five diagonals go, not just to the window's edge.
+        int since = 0;
+        bool pre_done = false;
+        while (i > 0 && j > 0) {
+            {   // make sure the window holding (i, j) is staged (wave-uniform)
+                const unsigned q0 = (unsigned)(i - 1);
+                const int s0 = (int)(q0 >> SH), k0 = (int)((q0 & (SR - 1)) >> RSH);
+                const int w0 = (j - 1 + k0) / WIN;
+                if (s0 != cur_s || w0 != cur_w) {
+                    if (!(s0 == pre_s && w0 == pre_w)) issue(w0 & 1, s0, w0);   // not the window already in flight / landed
+                    if (!(s0 == pre_s && w0 == pre_w && pre_done)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA is ordered for our ds_read by vmcnt
+                    cur_s = s0;
+                    cur_w = w0;
+                    pre_s = -1;
+                    pre_done = false;
+                    since = 0;
+                    if (w0 > 0) {
+                        issue((w0 - 1) & 1, s0, w0 - 1);
+                        pre_s = s0;
+                        pre_w = w0 - 1;
+                    }
+                } else if (pre_s >= 0 && !pre_done && ++since >= 3) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    pre_done = true;
+                }
+            }
+            // LDS addresses of this lane's cells (NOCODE when a cell is outside the matrix or the staged steps)
+            const int tlo = (pre_done ? cur_w - 1 : cur_w) * WIN, jj = j - dl;
+            const unsigned span = (unsigned)((cur_w + 1) * WIN - tlo);
+            auto staged = [&](int t) { return (unsigned)(t - tlo) < span; };
+            auto lds_at = [&](int t, int ql) { return ((t & (2 * WIN - 1)) << SH) | ql; };
+            int code[NV];
+            int qlo0 = 0, t0 = 0;
+            bool s0v = false;
+#pragma unroll
+            for (int r = 0; r <= A; ++r) {                                   // view A - r: the cell r rows above (i-d, j-d)
+                const int q = i - 1 - r - dl, ql = q & (SR - 1);
+                const bool same = (int)((unsigned)q >> SH) == cur_s;         // same stripe (false for rows above the matrix)
+                const int t = jj - 1 + (ql >> RSH);                          // its band step
+                code[A - r] = win[same && staged(t) && jj > 0 ? lds_at(t, ql) : NOCODE];
+                if (r == 0) {
+                    qlo0 = ql;
+                    t0 = t;
+                    s0v = same;
+                }
+            }
+#pragma unroll
+            for (int c = 1; c <= A; ++c)                                     // view A + c: the cell c columns left of (i-d, j-d)
+                code[A + c] = win[s0v && staged(t0 - c) && jj > c ? lds_at(t0 - c, qlo0) : NOCODE];
+            if (LOCAL && __builtin_amdgcn_readfirstlane(code[A]) == TB_STOP) {   // dp == 0 on the anchor, hw2.cpp:239
+                stopped = true;
+                break;
+            }
+            constexpr int CU = TbCode<LOCAL>::UP, CL = TbCode<LOCAL>::LEFT;
+            u64 dm[NV], um[NV], lm[NV];
+            uint32_t ob[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                dm[v] = __ballot(code[v] == TB_DIAG);
+                um[v] = __ballot(code[v] == CU);
+                lm[v] = __ballot(code[v] == CL);
+                ob[v] = __builtin_amdgcn_perm(0u, OPTAB, (uint32_t)code[v]);
+            }
+            int di, dj, sp, sn, vtmp;
+            u64 st;
+            // lanes p .. p + n - 1 store their op bytes at ops[cnt ..]; exec is put back at the end of the trip (the hops between are scalar)
+#define PWA_WV_A(K) "s_bfm_b64 exec, %[n], %[p]\n\t" "s_sub_u32 %[p], %[cnt], %[p]\n\t" "v_add_u32 %[tmp], %[lane], %[p]\n\t" "global_store_byte %[tmp], %[b" K "], %[ops]\n\t"
+            // one hop on view K: q = end of the run of 'd' from lane p, count = run + the gap op behind it (if any)
+#define PWA_WH_HOP(K)                                 \
+    "s_lshr_b64 %[t], %[d" K "], %[p]\n\t"            \
+    "s_not_b64 %[t], %[t]\n\t"                        \
+    "s_ff1_i32_b64 %[n], %[t]\n\t"                    \
+    "s_add_u32 %[q], %[p], %[n]\n\t"                  \
+    "s_or_b64 %[t], %[u" K "], %[l" K "]\n\t"         \
+    "s_bitcmp1_b64 %[t], %[q]\n\t"                    \
+    "s_addc_u32 %[n], %[n], 0\n\t"                    \
+    PWA_WV_A(K)                                       \
+    "s_add_u32 %[cnt], %[cnt], %[n]\n\t"
+            // view K = A + a, a < 0, cell (i+a-p, j-p): 'u' -> view KU same lane, 'l' -> view KL lane q+1; else the trip ends |a| rows up
+#define PWA_WH_NEG(K, KU, KL, RA)                                                                               \
+    "LV" K "_%=:\n\t" PWA_WH_HOP(K) "s_mov_b32 %[p], %[q]\n\t"                                                  \
+    "s_bitcmp1_b64 %[u" K "], %[q]\n\t"                                                                         \
+    "s_cbranch_scc1 LV" KU "_%=\n\t"                                                                            \
+    "s_add_u32 %[p], %[q], 1\n\t"                                                                               \
+    "s_bitcmp1_b64 %[l" K "], %[q]\n\t"                                                                         \
+    "s_cbranch_scc1 LV" KL "_%=\n\t"                                                                            \
+    "s_mov_b32 %[dj], %[q]\n\t"                                                                                 \
+    "s_add_u32 %[q], %[q], " RA "\n\t"                                                                          \
+    "s_branch LE_%=\n"
+            // a > 0, cell (i-p, j-a-p): 'l' -> view KL same lane, 'u' -> view KU lane q+1
+#define PWA_WH_POS(K, KU, KL, CA)                                                                               \
+    "LV" K "_%=:\n\t" PWA_WH_HOP(K) "s_mov_b32 %[p], %[q]\n\t"                                                  \
+    "s_bitcmp1_b64 %[l" K "], %[q]\n\t"                                                                         \
+    "s_cbranch_scc1 LV" KL "_%=\n\t"                                                                            \
+    "s_add_u32 %[p], %[q], 1\n\t"                                                                               \
+    "s_bitcmp1_b64 %[u" K "], %[q]\n\t"                                                                         \
+    "s_cbranch_scc1 LV" KU "_%=\n\t"                                                                            \
+    "s_add_u32 %[dj], %[q], " CA "\n\t"                                                                         \
+    "s_branch LE_%=\n"
+            // view A (the anchor's diagonal): 'u' / 'l' -> the neighbours, same lane
+#define PWA_WH_MID(K, KU, KL)                                                                                   \
+    "LV" K "_%=:\n\t" PWA_WH_HOP(K) "s_mov_b32 %[p], %[q]\n\t"                                                  \
+    "s_bitcmp1_b64 %[u" K "], %[q]\n\t"                                                                         \
+    "s_cbranch_scc1 LV" KU "_%=\n\t"                                                                            \
+    "s_bitcmp1_b64 %[l" K "], %[q]\n\t"                                                                         \
+    "s_cbranch_scc1 LV" KL "_%=\n\t"                                                                            \
+    "s_mov_b32 %[dj], %[q]\n\t"                                                                                 \
+    "s_branch LE_%=\n"
+            // the outermost views: a 'u' (view 0) / 'l' (view 2A) leaves the staged diagonals; its op is already stored
+#define PWA_WH_TOP(KL, RA)                                                                                      \
+    "LV0_%=:\n\t" PWA_WH_HOP("0") "s_add_u32 %[p], %[q], 1\n\t"                                                 \
+    "s_bitcmp1_b64 %[l0], %[q]\n\t"                                                                             \
+    "s_cbranch_scc1 LV" KL "_%=\n\t"                                                                            \
+    "s_mov_b32 %[dj], %[q]\n\t"                                                                                 \
+    "s_bitcmp1_b64 %[u0], %[q]\n\t"                                                                             \
+    "s_addc_u32 %[q], %[q], " RA "\n\t"                                                                         \
+    "s_branch LE_%=\n"
+#define PWA_WH_BOT(K, KU, CA)                                                                                   \
+    "LV" K "_%=:\n\t" PWA_WH_HOP(K) "s_add_u32 %[p], %[q], 1\n\t"                                               \
+    "s_bitcmp1_b64 %[u" K "], %[q]\n\t"                                                                         \
+    "s_cbranch_scc1 LV" KU "_%=\n\t"                                                                            \
+    "s_bitcmp1_b64 %[l" K "], %[q]\n\t"                                                                         \
+    "s_addc_u32 %[dj], %[q], " CA "\n"
+#define PWA_WH_OUT [cnt] "+s"(cnt), [q] "=&s"(di), [dj] "=&s"(dj), [p] "=&s"(sp), [n] "=&s"(sn), [t] "=&s"(st), [tmp] "=&v"(vtmp)
+#define PWA_WH_IN(K, V) [d##K] "s"(dm[V]), [u##K] "s"(um[V]), [l##K] "s"(lm[V]), [b##K] "v"(ob[V])
+#if PWA_WALK_A == 4
+            {
+                asm volatile("s_mov_b32 %[p], 0\n\t"
+                             "s_branch LV4_%=\n"
+                             PWA_WH_TOP("1", "4") PWA_WH_NEG("1", "0", "2", "3") PWA_WH_NEG("2", "1", "3", "2") PWA_WH_NEG("3", "2", "4", "1")
+                             PWA_WH_MID("4", "3", "5")
+                             PWA_WH_POS("5", "4", "6", "1") PWA_WH_POS("6", "5", "7", "2") PWA_WH_POS("7", "6", "8", "3") PWA_WH_BOT("8", "7", "4")
+                             "LE_%=:\n\t"
+                             "s_mov_b64 exec, -1"
+                             : PWA_WH_OUT
+                             : PWA_WH_IN(0, 0), PWA_WH_IN(1, 1), PWA_WH_IN(2, 2), PWA_WH_IN(3, 3), PWA_WH_IN(4, 4), PWA_WH_IN(5, 5), PWA_WH_IN(6, 6),
+                               PWA_WH_IN(7, 7), PWA_WH_IN(8, 8), [lane] "v"(lane), [ops] "s"(ops)
+                             : "memory", "scc");
+            }
+#else
+            {
+                static_assert(A == 3, "the hop code is written out for seven or nine views");
+                asm volatile("s_mov_b32 %[p], 0\n\t"
+                             "s_branch LV3_%=\n"
+                             PWA_WH_TOP("1", "3") PWA_WH_NEG("1", "0", "2", "2") PWA_WH_NEG("2", "1", "3", "1")
+                             PWA_WH_MID("3", "2", "4")
+                             PWA_WH_POS("4", "3", "5", "1") PWA_WH_POS("5", "4", "6", "2") PWA_WH_BOT("6", "5", "3")
+                             "LE_%=:\n\t"
+                             "s_mov_b64 exec, -1"
+                             : PWA_WH_OUT
+                             : PWA_WH_IN(0, 0), PWA_WH_IN(1, 1), PWA_WH_IN(2, 2), PWA_WH_IN(3, 3), PWA_WH_IN(4, 4), PWA_WH_IN(5, 5), PWA_WH_IN(6, 6),
+                               [lane] "v"(lane), [ops] "s"(ops)
+                             : "memory", "scc");
+            }
+#endif
+#undef PWA_WH_MID
+#undef PWA_WH_TOP
+#undef PWA_WH_BOT
+#undef PWA_WH_OUT
+#undef PWA_WH_IN
+#undef PWA_WH_HOP
+#undef PWA_WV_A
+#undef PWA_WH_NEG
+#undef PWA_WH_POS
+            // the trip ended di rows and dj columns behind the anchor
+            if ((di | dj) == 0) {   // cannot happen (the anchor's window is staged): never spin on the GPU
+                walk_fault = true;
+                break;
+            }
+            i -= di;
+            j -= dj;
+            ++best_run;   // (op-list walk: `overlap` reports the trips, for PWA_DEBUG)
+        }
+    }
+    while (!OPS && i > 0 && j > 0) {
         {   // make sure the window holding (i, j) is staged (wave-uniform)
             const unsigned q0 = (unsigned)(i - 1);
             const int s0 = (int)(q0 / (64 * RL)), k0 = (int)((q0 % (64 * RL)) / RL);
@@ -931,7 +1140,7 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         res->start_j = (uint32_t)j;
         res->n_ops = cnt;
         res->overlap = best_run;
-        res->overflow = cnt > P.ops_cap ? 1u : 0u;   // cannot happen: a walk has at most n + m ops
+        res->overflow = (cnt > P.ops_cap || walk_fault) ? 1u : 0u;   // cannot happen: a walk has at most n + m ops
     }
 }
 

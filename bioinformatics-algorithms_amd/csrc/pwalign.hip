@@ -1808,6 +1808,11 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         if (want_ops && ch.tiled && ch.span) HIPC(ctx, hipMemcpy(ops + ops_lo, d_ops, ch.span, hipMemcpyDeviceToHost));   // straight into the caller's list
         if (want_ops && !ch.tiled) HIPC(ctx, hipMemcpy(host_ops.data(), d_ops, opsb, hipMemcpyDeviceToHost));
         mark("results (+ ops) to host");
+        if (dbg && want_ops) {   // the op-list walk leaves its LDS round trips in `overlap` (unused by that walk)
+            uint64_t trips = 0, nops = 0;
+            for (uint64_t q = 0; q < nc; ++q) trips += res[q].overlap, nops += res[q].n_ops;
+            std::fprintf(stderr, "[pwa] walk: %llu ops in %llu trips\n", (unsigned long long)nops, (unsigned long long)trips);
+        }
         for (uint64_t q = 0; q < nc; ++q) {
             const uint64_t k = k0 + q, n = slen(pair_a[k]), m = slen(pair_b[k]);
             uint64_t cnt = res[q].n_ops;
