@@ -400,7 +400,11 @@ struct PairLaunch {
         n_stripes = n_stripes_total;
         // Tasks come off the queue in global order, so correctness does not depend on how many workgroups
         // are resident.  One workgroup = W compute waves + 1 helper wave.
-        grid = (uint32_t)std::min<uint64_t>(tl.size(), (uint64_t)ctx->num_cu * (g.w == 1 ? 8 : 3));
+        // [gpu] single-stripe batches (4096 pairs 150 x 10k, NW + band): 8 workgroups per CU 4.11 ms, 12 or 16: 3.76 ms (three
+        // compute waves per SIMD fill the issue slots two leave open); the HBM-bound SW + score-band batch does not care
+        int per_cu = g.w == 1 ? 12 : 3;
+        if (const char* e = std::getenv("PWA_WG_PER_CU")) per_cu = std::max(1, std::atoi(e));   // experiments only
+        grid = (uint32_t)std::min<uint64_t>(tl.size(), (uint64_t)ctx->num_cu * per_cu);
         return PWA_OK;
     }
     // enqueue: zero the queue / progress words, fill, then the walk (or only the end-cell pick)
