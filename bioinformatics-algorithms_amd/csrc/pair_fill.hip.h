@@ -460,6 +460,9 @@ __device__ __forceinline__ void keyed_chunk(const int t0, const int lane, const 
     tch = tn;
 }
 
+#ifndef PWA_HELPER_NAP
+#define PWA_HELPER_NAP 32   // x 64 cycles
+#endif
 #ifndef PWA_STEP_UNROLL
 #define PWA_STEP_UNROLL 8   // [gpu] C5 fill: 4 -> 21.1 ms, 8 -> 20.1 ms, 16 -> 23.2 ms
 #endif
@@ -585,7 +588,10 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                 if (progress) {
                     idle = 0;
                 } else {
-                    __builtin_amdgcn_s_sleep(2);
+                    // a helper that only stages text for its own workgroup is hundreds of columns ahead of it: long naps (a batch
+                    // of single-stripe pairs has three of these spinning on every SIMD next to the waves that do the work)
+                    if (top_global || bot_global) __builtin_amdgcn_s_sleep(2);
+                    else __builtin_amdgcn_s_sleep(PWA_HELPER_NAP);
                     if (++idle > spin_limit) {   // bounded: flag the failure, let the host report it
                         if (lane == 0) __hip_atomic_store((g_u32*)(G.queue + 1), 1u, PWA_RLX_AGENT);
                         break;

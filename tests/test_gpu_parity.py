@@ -851,6 +851,63 @@ def test_pair_engine_shapes_around_every_boundary(ctx, n_class, monkeypatch):
                 monkeypatch.delenv(k, raising=False)
 
 
+def _indel_blocks(rng, s, n_events, max_len):
+    """s with n_events blocks of up to max_len symbols cut out or spliced in: long runs of 'u' / 'l' in the optimal path."""
+    out = bytearray(s)
+    for _ in range(n_events):
+        at = rng.randrange(0, max(1, len(out)))
+        ln = rng.randint(1, max_len)
+        if rng.random() < 0.5:
+            del out[at:at + ln]
+        else:
+            out[at:at] = bytes(rng.choice(b"ACGT") for _ in range(ln))
+    return bytes(out)
+
+
+@pytest.mark.parametrize("force_rl", [None, "4", "2"])
+def test_walk_across_gap_runs_drift_and_ties(ctx, force_rl, monkeypatch):
+    """The op-list walk (r02) follows the path over seven diagonals per LDS round trip and ends a trip when the path drifts off them,
+    leaves the staged windows or the stripe: paths with long runs of gaps in one direction, zig-zags of single gaps, tie-riddled
+    homopolymers and scorings that prefer gaps, over one- and many-stripe patterns -- every op list against the oracle."""
+    if force_rl:
+        monkeypatch.setenv("PWA_FORCE_RL", force_rl)
+    rng = random.Random(77)
+    seqs, pa, pb = [], [], []
+
+    def add(p, t):
+        seqs.extend([p, t])
+        pa.append(len(seqs) - 2)
+        pb.append(len(seqs) - 1)
+
+    for n in (90, 200, 700, 1500):
+        base = bytes(rng.choice(b"ACGT") for _ in range(n))
+        add(base, _indel_blocks(rng, base, 6, 5))            # short gap runs: the path wanders over a few diagonals
+        add(base, _indel_blocks(rng, base, 5, 60))           # long runs: off the seven diagonals at once
+        add(_indel_blocks(rng, base, 4, 150), base)
+        add(base, base[n // 3:] + base[:n // 3])             # a rotation: two long gap runs at the ends
+        zig = bytearray()
+        for k, c in enumerate(base):                         # single-symbol indels every few columns
+            if k % 7 == 3:
+                continue
+            zig.append(c)
+            if k % 5 == 1:
+                zig.append(rng.choice(b"ACGT"))
+        add(base, bytes(zig))
+        add(b"A" * n, b"A" * (n + 37))                       # ties everywhere: the reference's order of preference decides
+        add(b"AC" * (n // 2), b"CA" * (n // 2 + 11))
+        add(base, bytes(rng.choice(b"ACGT") for _ in range(n // 2 + 5)))
+    try:
+        for mode in ("nw", "sw"):
+            for sc in [(1, -1, -1), (1, -3, -1), (2, -1, -3), (0, 0, 0), (1, 1, 1), (-1, 2, 1), (1, -1, 0)]:
+                res = ctx.align_batch(mode, seqs, pa, pb, *sc)
+                for k, r in enumerate(res):
+                    want = O.align(mode, seqs[pa[k]], seqs[pb[k]], *sc, compact=True)
+                    assert (r["score"], r["ops"], tuple(r["end"]), tuple(r["start"])) == \
+                        (want["score"], want["ops"], tuple(want["end"]), tuple(want["start"])), (force_rl, mode, sc, k, len(seqs[pa[k]]), len(seqs[pb[k]]))
+    finally:
+        monkeypatch.delenv("PWA_FORCE_RL", raising=False)
+
+
 def test_pipeline_handoff_under_uneven_concurrent_load(ctx):
     """Many multi-super-stripe pairs of very different shapes in ONE launch: every inter-workgroup hand-off
     (helper wave, sc1 rows + progress counters) runs while other workgroups stream bands at different rates.
