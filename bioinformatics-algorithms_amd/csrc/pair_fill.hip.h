@@ -854,13 +854,13 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         //   view a = 0:       (i-d, j-d)        the diagonal through the anchor (i, j),
         //   view a = -1..-A:  (i+a-d, j-d)      the ones the path is on after |a| net 'u',
         //   view a = +1..+A:  (i-d, j-a-d)      ... after a net 'l',
-        // each view becomes three ballot masks (d / u / l) and a vector of op bytes, and the walk then hops between the views on
+        // each view becomes three ballot masks ('d' / gap / 'l') and a vector of op bytes, and the walk then hops between the views on
         // SCALAR bit tests alone, written out by hand (hipcc turns the state machine into a loop over state flags, ~32
         // instructions per hop).  On view a the walk stands on lane p: the run of 'd' codes from p on ends at lane q; lanes
         // p .. q (q included when it holds 'u' / 'l') store their op bytes to ops[cnt ..] (hw2.cpp:164-179 / 240-255) under
         // exec = s_bfm(count, p); 'u' moves to view a-1 (same lane while a <= 0, else lane q+1), 'l' to view a+1 (same lane
         // while a >= 0, else lane q+1); anything else -- a cell outside the staged diagonals, the staged windows or the matrix, a
-        // local alignment's zero cell, lane 63 -- ends the trip there.  18 instructions per hop against ~140 per trip.
+        // local alignment's zero cell, lane 63 -- ends the trip there.  17 instructions per hop against ~130 per trip.
         // A lone wave issues one instruction per ~5.4 cycles whatever its kind, so the walk is priced in instructions per op:
         // the one-diagonal loop below (kept for the overlap walk) spends ~70 per trip = per non-diagonal op, 206 cycles per op
         // on C5.  [gpu] C5 walk (116 001 ops): 9.9 ms one diagonal (32 k trips); three views, hipcc's hop code 6.7 ms; hand-written
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
             {   // make sure the window holding (i, j) is staged (wave-uniform)
                 const unsigned q0 = (unsigned)(i - 1);
                 const int s0 = (int)(q0 >> SH), k0 = (int)((q0 & (SR - 1)) >> RSH);
-                const int w0 = (j - 1 + k0) / WIN;
+                const int w0 = (int)((unsigned)(j - 1 + k0) / (unsigned)WIN);
                 if (s0 != cur_s || w0 != cur_w) {
                     if (!(s0 == pre_s && w0 == pre_w)) issue(w0 & 1, s0, w0);   // not the window already in flight / landed
                     if (!(s0 == pre_s && w0 == pre_w && pre_done)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA is ordered for our ds_read by vmcnt
@@ -936,13 +936,14 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
                 stopped = true;
                 break;
             }
-            constexpr int CU = TbCode<LOCAL>::UP, CL = TbCode<LOCAL>::LEFT;
-            u64 dm[NV], um[NV], lm[NV];
+            constexpr int CL = TbCode<LOCAL>::LEFT;
+            static_assert(TbCode<LOCAL>::UP < 2 && CL < 2 && TB_DIAG == 2 && TB_STOP == 3, "the two gap codes are the values below 2");
+            u64 dm[NV], gm[NV], lm[NV];   // 'd', 'u' or 'l', 'l'
             uint32_t ob[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 dm[v] = __ballot(code[v] == TB_DIAG);
-                um[v] = __ballot(code[v] == CU);
+                gm[v] = __ballot((unsigned)code[v] < 2u);
                 lm[v] = __ballot(code[v] == CL);
                 ob[v] = __builtin_amdgcn_perm(0u, OPTAB, (uint32_t)code[v]);
             }
@@ -956,19 +957,19 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
     "s_not_b64 %[t], %[t]\n\t"                        \
     "s_ff1_i32_b64 %[n], %[t]\n\t"                    \
     "s_add_u32 %[q], %[p], %[n]\n\t"                  \
-    "s_or_b64 %[t], %[u" K "], %[l" K "]\n\t"         \
-    "s_bitcmp1_b64 %[t], %[q]\n\t"                    \
+    "s_bitcmp1_b64 %[g" K "], %[q]\n\t"               \
     "s_addc_u32 %[n], %[n], 0\n\t"                    \
     PWA_WV_A(K)                                       \
     "s_add_u32 %[cnt], %[cnt], %[n]\n\t"
-            // view K = A + a, a < 0, cell (i+a-p, j-p): 'u' -> view KU same lane, 'l' -> view KL lane q+1; else the trip ends |a| rows up
+            // (below: a gap code that is not 'l' is 'u')
+            // view K = A + a, a < 0, cell (i+a-p, j-p): 'l' -> view KL lane q+1, 'u' -> view KU same lane; else the trip ends |a| rows up
 #define PWA_WH_NEG(K, KU, KL, RA)                                                                               \
-    "LV" K "_%=:\n\t" PWA_WH_HOP(K) "s_mov_b32 %[p], %[q]\n\t"                                                  \
-    "s_bitcmp1_b64 %[u" K "], %[q]\n\t"                                                                         \
-    "s_cbranch_scc1 LV" KU "_%=\n\t"                                                                            \
-    "s_add_u32 %[p], %[q], 1\n\t"                                                                               \
+    "LV" K "_%=:\n\t" PWA_WH_HOP(K) "s_add_u32 %[p], %[q], 1\n\t"                                               \
     "s_bitcmp1_b64 %[l" K "], %[q]\n\t"                                                                         \
     "s_cbranch_scc1 LV" KL "_%=\n\t"                                                                            \
+    "s_mov_b32 %[p], %[q]\n\t"                                                                                  \
+    "s_bitcmp1_b64 %[g" K "], %[q]\n\t"                                                                         \
+    "s_cbranch_scc1 LV" KU "_%=\n\t"                                                                            \
     "s_mov_b32 %[dj], %[q]\n\t"                                                                                 \
     "s_add_u32 %[q], %[q], " RA "\n\t"                                                                          \
     "s_branch LE_%=\n"
@@ -978,17 +979,17 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
     "s_bitcmp1_b64 %[l" K "], %[q]\n\t"                                                                         \
     "s_cbranch_scc1 LV" KL "_%=\n\t"                                                                            \
     "s_add_u32 %[p], %[q], 1\n\t"                                                                               \
-    "s_bitcmp1_b64 %[u" K "], %[q]\n\t"                                                                         \
+    "s_bitcmp1_b64 %[g" K "], %[q]\n\t"                                                                         \
     "s_cbranch_scc1 LV" KU "_%=\n\t"                                                                            \
     "s_add_u32 %[dj], %[q], " CA "\n\t"                                                                         \
     "s_branch LE_%=\n"
             // view A (the anchor's diagonal): 'u' / 'l' -> the neighbours, same lane
 #define PWA_WH_MID(K, KU, KL)                                                                                   \
     "LV" K "_%=:\n\t" PWA_WH_HOP(K) "s_mov_b32 %[p], %[q]\n\t"                                                  \
-    "s_bitcmp1_b64 %[u" K "], %[q]\n\t"                                                                         \
-    "s_cbranch_scc1 LV" KU "_%=\n\t"                                                                            \
     "s_bitcmp1_b64 %[l" K "], %[q]\n\t"                                                                         \
     "s_cbranch_scc1 LV" KL "_%=\n\t"                                                                            \
+    "s_bitcmp1_b64 %[g" K "], %[q]\n\t"                                                                         \
+    "s_cbranch_scc1 LV" KU "_%=\n\t"                                                                            \
     "s_mov_b32 %[dj], %[q]\n\t"                                                                                 \
     "s_branch LE_%=\n"
             // the outermost views: a 'u' (view 0) / 'l' (view 2A) leaves the staged diagonals; its op is already stored
@@ -997,24 +998,26 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
     "s_bitcmp1_b64 %[l0], %[q]\n\t"                                                                             \
     "s_cbranch_scc1 LV" KL "_%=\n\t"                                                                            \
     "s_mov_b32 %[dj], %[q]\n\t"                                                                                 \
-    "s_bitcmp1_b64 %[u0], %[q]\n\t"                                                                             \
+    "s_bitcmp1_b64 %[g0], %[q]\n\t"                                                                             \
     "s_addc_u32 %[q], %[q], " RA "\n\t"                                                                         \
     "s_branch LE_%=\n"
-#define PWA_WH_BOT(K, KU, CA)                                                                                   \
+#define PWA_WH_BOT(K, KU, CA, CA1)                                                                              \
     "LV" K "_%=:\n\t" PWA_WH_HOP(K) "s_add_u32 %[p], %[q], 1\n\t"                                               \
-    "s_bitcmp1_b64 %[u" K "], %[q]\n\t"                                                                         \
-    "s_cbranch_scc1 LV" KU "_%=\n\t"                                                                            \
+    "s_add_u32 %[dj], %[q], " CA1 "\n\t"                                                                        \
     "s_bitcmp1_b64 %[l" K "], %[q]\n\t"                                                                         \
-    "s_addc_u32 %[dj], %[q], " CA "\n"
+    "s_cbranch_scc1 LE_%=\n\t"                                                                                  \
+    "s_bitcmp1_b64 %[g" K "], %[q]\n\t"                                                                         \
+    "s_cbranch_scc1 LV" KU "_%=\n\t"                                                                            \
+    "s_add_u32 %[dj], %[q], " CA "\n"
 #define PWA_WH_OUT [cnt] "+s"(cnt), [q] "=&s"(di), [dj] "=&s"(dj), [p] "=&s"(sp), [n] "=&s"(sn), [t] "=&s"(st), [tmp] "=&v"(vtmp)
-#define PWA_WH_IN(K, V) [d##K] "s"(dm[V]), [u##K] "s"(um[V]), [l##K] "s"(lm[V]), [b##K] "v"(ob[V])
+#define PWA_WH_IN(K, V) [d##K] "s"(dm[V]), [g##K] "s"(gm[V]), [l##K] "s"(lm[V]), [b##K] "v"(ob[V])
 #if PWA_WALK_A == 4
             {
                 asm volatile("s_mov_b32 %[p], 0\n\t"
                              "s_branch LV4_%=\n"
                              PWA_WH_TOP("1", "4") PWA_WH_NEG("1", "0", "2", "3") PWA_WH_NEG("2", "1", "3", "2") PWA_WH_NEG("3", "2", "4", "1")
                              PWA_WH_MID("4", "3", "5")
-                             PWA_WH_POS("5", "4", "6", "1") PWA_WH_POS("6", "5", "7", "2") PWA_WH_POS("7", "6", "8", "3") PWA_WH_BOT("8", "7", "4")
+                             PWA_WH_POS("5", "4", "6", "1") PWA_WH_POS("6", "5", "7", "2") PWA_WH_POS("7", "6", "8", "3") PWA_WH_BOT("8", "7", "4", "5")
                              "LE_%=:\n\t"
                              "s_mov_b64 exec, -1"
                              : PWA_WH_OUT
@@ -1029,7 +1032,7 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
                              "s_branch LV3_%=\n"
                              PWA_WH_TOP("1", "3") PWA_WH_NEG("1", "0", "2", "2") PWA_WH_NEG("2", "1", "3", "1")
                              PWA_WH_MID("3", "2", "4")
-                             PWA_WH_POS("4", "3", "5", "1") PWA_WH_POS("5", "4", "6", "2") PWA_WH_BOT("6", "5", "3")
+                             PWA_WH_POS("4", "3", "5", "1") PWA_WH_POS("5", "4", "6", "2") PWA_WH_BOT("6", "5", "3", "4")
                              "LE_%=:\n\t"
                              "s_mov_b64 exec, -1"
                              : PWA_WH_OUT
