@@ -55,6 +55,12 @@ OP(k_xor, "v_xor_b32 %0, %1, %2")
 OP(k_mov, "v_mov_b32 %0, %2")
 OP(k_sdwa, "v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
 OP(k_perm, "v_perm_b32 %0, %1, %2, %3")
+OP(k_dot4i8, "v_dot4_i32_i8 %0, %1, %2, %3")
+OP(k_dot4u8, "v_dot4_u32_u8 %0, %1, %2, %3")
+OP(k_dot8i4, "v_dot8_i32_i4 %0, %1, %2, %3")
+OP(k_dot2i16, "v_dot2_i32_i16 %0, %1, %2, %3")
+OP(k_sad8, "v_sad_u8 %0, %1, %2, %3")
+OP(k_bfei, "v_bfe_i32 %0, %1, 8, 8")
 OP(k_pkmax, "v_pk_max_i16 %0, %1, %2")
 OP(k_pkadd, "v_pk_add_i16 %0, %1, %2")
 OP(k_pksubc, "v_pk_sub_u16 %0, %1, %2 clamp")
@@ -148,6 +154,8 @@ int main(int argc, char** argv) {
         {"v_sub_u16 clamp", k_subu16c, 1}, {"v_add_i16 clamp", k_addi16c, 1}, {"v_mad_u16", k_madu16, 1}, {"v_max3_f16", k_max3f16, 1}, {"v_max_f16", k_maxf16, 1},
         {"v_add_u16_sdwa sext(byte)", k_addu16sdwa, 1}, {"v_addc_co_u32", k_addcou32, 1}, {"v_subrev_u32", k_subrev, 1}, {"v_bfi_b32", k_bfi2, 1},
         {"v_and_or_b32", k_andor, 1}, {"idx_on+4 v_add+idx_off /add", k_idx4, 1},
+        {"v_dot4_i32_i8", k_dot4i8, 1}, {"v_dot4_u32_u8", k_dot4u8, 1}, {"v_dot8_i32_i4", k_dot8i4, 1}, {"v_dot2_i32_i16", k_dot2i16, 1},
+        {"v_sad_u8", k_sad8, 1}, {"v_bfe_i32", k_bfei, 1},
         {"SW cell, profile form /cell", k_cell4, 1}, {"SW cell, table form   /cell", k_cell4old, 1}, {"s_nop 0", k_nop, 1}};
     struct { const char* n; kfn f; int chain, total; } dt_[] = {
         {"v_add_u32 chain", d_add, 4, 4}, {"v_and/v_or chain", d_and, 4, 4}, {"v_max3_i32 chain", d_max3, 4, 4}, {"v_add_u32_sdwa chain", d_sdwa, 4, 4},
