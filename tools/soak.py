@@ -1,0 +1,41 @@
+"""Stability soak of the pair engine on one GPU: the same inputs many times, every result compared with the first one
+(score, op list hash, cells) and the first one with the oracle where that is cheap.  usage: python tools/soak.py [reps]"""
+import hashlib, importlib.util, os, sys, time
+import torch  # noqa: F401
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+spec = importlib.util.spec_from_file_location("pwa_pkg", os.path.join(ROOT, "bioinformatics-algorithms_amd", "__init__.py"))
+pkg = importlib.util.module_from_spec(spec); spec.loader.exec_module(pkg)
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from bench import gen
+import oracle_lib as O
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+ctx = pkg.Context(0)
+def key(r): return (r["score"], hashlib.sha256(r["ops"]).hexdigest(), tuple(r["end"]), tuple(r["start"]))
+t0 = time.time()
+# single pairs: C5 (NW 100k), C2 (SW 10k), a 30k x 7k SW and a 3k x 40k NW
+cases = [("nw", gen(1, 0, 0, 100000), gen(1, 1, 0, 100000), reps), ("sw", gen(1, 0, 0, 10000), gen(1, 1, 0, 10000), reps * 10),
+         ("sw", gen(2, 0, 0, 30000), gen(2, 1, 0, 7000), reps * 3), ("nw", gen(3, 0, 0, 3000), gen(3, 1, 0, 40000), reps * 3)]
+for mode, a, b, n in cases:
+    first = key(ctx.align(mode, a, b, 1, -1, -1, raw=True))
+    if len(a) * len(b) <= 3e8:
+        w = O.align(mode, a, b, 1, -1, -1, compact=True)
+        assert first == (w["score"], hashlib.sha256(w["ops"]).hexdigest(), tuple(w["end"]), tuple(w["start"])), "first result differs from the oracle"
+    for k in range(n):
+        assert key(ctx.align(mode, a, b, 1, -1, -1, raw=True)) == first, (mode, len(a), len(b), k)
+    print("%s %d x %d: %d identical runs, %.1f s" % (mode, len(a), len(b), n + 1, time.time() - t0), flush=True)
+# batches: 512 pairs of mixed lengths (one to eight stripes), NW and SW
+import random
+rng = random.Random(5)
+seqs, pa, pb = [], [], []
+for k in range(512):
+    n, m = rng.choice([90, 150, 300, 700, 1500, 2000]), rng.choice([500, 1200, 3000])
+    seqs += [gen(7, 0, k, n), gen(7, 1, k, m)]; pa.append(2 * k); pb.append(2 * k + 1)
+for mode in ("nw", "sw"):
+    first = [key(r) for r in ctx.align_batch(mode, seqs, pa, pb, 1, -1, -1)]
+    for k in range(0, 512, 37):
+        w = O.align(mode, seqs[pa[k]], seqs[pb[k]], 1, -1, -1, compact=True)
+        assert first[k] == (w["score"], hashlib.sha256(w["ops"]).hexdigest(), tuple(w["end"]), tuple(w["start"]))
+    for it in range(reps):
+        assert [key(r) for r in ctx.align_batch(mode, seqs, pa, pb, 1, -1, -1)] == first, (mode, it)
+    print("batch %s: %d identical runs, %.1f s" % (mode, reps + 1, time.time() - t0), flush=True)
+print("soak ok")
