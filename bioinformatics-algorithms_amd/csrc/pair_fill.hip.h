@@ -829,8 +829,18 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
     // the end of its stripe or of the band; the host pads the band allocation by one window.
     auto issue = [&](int buf, int s, int w) {
         const size_t off0 = ((size_t)s * T + (size_t)w * WIN) * STEP_BYTES;
+        // (four pieces per address pair: the instruction's immediate offset moves the global and the LDS address alike)
 #pragma unroll
-        for (int u = 0; u < WB / 1024; ++u)
+        for (int u = 0; u < WB / 4096; ++u) {
+            const PWA_GLOBAL uint32_t* g = (const PWA_GLOBAL uint32_t*)(tb + off0 + (size_t)u * 4096 + lane * 16);
+            __attribute__((address_space(3))) uint32_t* l = (__attribute__((address_space(3))) uint32_t*)(win + buf * WB + u * 4096);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+        }
+#pragma unroll
+        for (int u = (WB / 4096) * 4; u < WB / 1024; ++u)   // (RL = 2: 8 KiB windows are whole multiples of 4 KiB as well; nothing left)
             __builtin_amdgcn_global_load_lds((const PWA_GLOBAL uint32_t*)(tb + off0 + (size_t)u * 1024 + lane * 16),
                                              (__attribute__((address_space(3))) uint32_t*)(win + buf * WB + u * 1024), 16, 0, 0);
     };
