@@ -51,8 +51,60 @@ struct PinnedBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Test / diagnostic switches (include/pwalign.h, "Environment switches"): environment variables read ONCE, by
+// pwa_ctx_create, into the context.  No entry point consults the environment afterwards; a test that wants another
+// setting creates a fresh context.
+struct Knobs {
+    bool debug = false, probe = false;          // PWA_DEBUG, PWA_PROBE: host-side phase times on stderr, nop-kernel probes
+    int force_rl = 0, force_w = 0;              // PWA_FORCE_RL (2 | 3 | 4), PWA_FORCE_W (1 | 4): geometry of the stripe engine
+    int wg_per_cu = 0;                          // PWA_WG_PER_CU: workgroups per CU of a stripe-engine launch
+    bool no_lds_pad = false;                    // PWA_NO_LDS_PAD
+    std::string stamps;                         // PWA_STAMPS=<file>: per-stripe time stamps of the fill
+    int trace_stripe = -1;                      // PWA_TRACE_STRIPE
+    bool no_packed_dist = false;                // PWA_NO_PACKED_DIST: hw4 pass in its two-value form
+    int paired = -1;                            // PWA_PAIRED: two-strip tasks as two waves with an LDS hand-off (opt-in)
+    int force_lanes = -1;                       // PWA_FORCE_LANES=0: never the per-lane-text kernels
+    int force_r = 0, force_mode = -1;           // PWA_FORCE_R, PWA_FORCE_MODE: strip height / kernel form of the strip engine
+    uint64_t arena_limit = 0;                   // PWA_ARENA_LIMIT: bytes of sequence arena per run of the one-shot calls (tests)
+    uint64_t lane_rows_limit = 0;               // PWA_LANE_ROWS_LIMIT: bytes of per-lane text rows per batch object (tests)
+    bool no_pair_table = false;                 // PWA_NO_PAIR_TABLE: traceback fills on raw bytes (compare + select)
+    bool no_keyed_tb = false;                   // PWA_NO_KEYED_TB: traceback fills in the plain int32 form
+    bool no_gap_shift = false;                  // PWA_NO_GAP_SHIFT: global traceback fills in H, not G = H - gap (i + j)
+    bool no_tiled_ops = false;                  // PWA_NO_TILED_OPS: op lists through the staging copy
+    int scores_route = -1;                      // PWA_SCORES_ROUTE: 0 = every pair on the strip engine, 1 = every pair on the stripe
+                                                // engine, unset = by estimated cost (batch_create_impl)
+    int tb_engine = -1;                         // PWA_TB_ENGINE: 0 = stripe engine only, 1 = mini-stripe engine wherever it applies,
+                                                // unset = by pattern length
+    void read() {
+        auto flag = [](const char* n) { return std::getenv(n) != nullptr; };
+        auto num = [](const char* n, int dflt) { const char* e = std::getenv(n); return e ? std::atoi(e) : dflt; };
+        debug = flag("PWA_DEBUG");
+        probe = flag("PWA_PROBE");
+        force_rl = num("PWA_FORCE_RL", 0);
+        force_w = num("PWA_FORCE_W", 0);
+        wg_per_cu = num("PWA_WG_PER_CU", 0);
+        no_lds_pad = flag("PWA_NO_LDS_PAD");
+        if (const char* e = std::getenv("PWA_STAMPS")) stamps = e;
+        trace_stripe = num("PWA_TRACE_STRIPE", -1);
+        no_packed_dist = flag("PWA_NO_PACKED_DIST");
+        paired = num("PWA_PAIRED", -1);
+        force_lanes = num("PWA_FORCE_LANES", -1);
+        force_r = num("PWA_FORCE_R", 0);
+        force_mode = num("PWA_FORCE_MODE", -1);
+        if (const char* e = std::getenv("PWA_ARENA_LIMIT")) arena_limit = std::max<uint64_t>(1024, std::strtoull(e, nullptr, 10));
+        if (const char* e = std::getenv("PWA_LANE_ROWS_LIMIT")) lane_rows_limit = std::max<uint64_t>(1024, std::strtoull(e, nullptr, 10));
+        no_pair_table = flag("PWA_NO_PAIR_TABLE");
+        no_keyed_tb = flag("PWA_NO_KEYED_TB");
+        no_gap_shift = flag("PWA_NO_GAP_SHIFT");
+        no_tiled_ops = flag("PWA_NO_TILED_OPS");
+        scores_route = num("PWA_SCORES_ROUTE", -1);
+        tb_engine = num("PWA_TB_ENGINE", -1);
+    }
+};
+
 // ------------------------------------------------------------------------------------ context
 struct pwa_ctx {
+    Knobs knobs;
     int device = 0;
     int num_cu = 256;
     hipStream_t stream = nullptr;
@@ -294,20 +346,20 @@ inline int32_t wrap_mul(int64_t a, int32_t b) { return (int32_t)((uint32_t)a * (
 struct PairGeom {
     int rl, w;
 };
-PairGeom choose_geom(uint64_t max_n, bool keyed = true, bool keyed_tb = false) {
+PairGeom choose_geom(const Knobs& kn, uint64_t max_n, bool keyed = true, bool keyed_tb = false) {
     // (W = 3 -- three stripes + the helper = one wave per SIMD -- was measured in r02: no gain over W = 4, the stripes behind the
     // first workgroup run ~5-9 % slower than the first either way: they run at the edge of what their producer has posted.)
     PairGeom g{max_n <= 32768 ? 2 : 4, 4};   // [gpu] 10k x 10k: RL=2 2.27 ms vs RL=4 2.52; 100k x 100k: RL=4 20.9 ms vs RL=2 22.0
     // 129..256 rows: ONE 256-row stripe (W = 1, 8 workgroups per CU) instead of two 128-row stripes in a 4-stripe
     // workgroup with two idle waves; [gpu] 4096 pairs 150 x 10k: fill 8.2 -> 7.3 ms, with the score band 12.1 -> 10.4 ms
     if (max_n > 128 && max_n <= 256) g.rl = 4;
-    if (const char* e = std::getenv("PWA_FORCE_RL")) g.rl = std::atoi(e) == 2 ? 2 : 4;   // experiments only
+    if (kn.force_rl) g.rl = kn.force_rl == 2 ? 2 : 4;   // experiments only
     if (!keyed) g.rl = 4;   // the plain int32 traceback form exists for RL = 4 only (pair_kernels.hip)
     if ((max_n + 64 * g.rl - 1) / (64 * g.rl) <= 1) g.w = 1;
     // (W = 8 was built and measured in r02: nine waves on a CU's four SIMDs share issue slots, a step goes from 197 to 317
     // cycles -- a workgroup lives on one CU, so four compute waves is the most that keeps one stripe per SIMD)
     (void)keyed_tb;
-    if (const char* e = std::getenv("PWA_FORCE_W")) g.w = std::atoi(e) == 1 ? 1 : 4;
+    if (kn.force_w) g.w = kn.force_w == 1 ? 1 : 4;
     return g;
 }
 pair_kernel_t pair_fill_fn(PairGeom g, bool local, bool tb, bool sband, bool perm, bool keyed, bool gap0) {
@@ -403,7 +455,7 @@ struct PairLaunch {
         // [gpu] single-stripe batches (4096 pairs 150 x 10k, NW + band): 8 workgroups per CU 4.11 ms, 12 or 16: 3.76 ms (three
         // compute waves per SIMD fill the issue slots two leave open); the HBM-bound SW + score-band batch does not care
         int per_cu = g.w == 1 ? 12 : 3;
-        if (const char* e = std::getenv("PWA_WG_PER_CU")) per_cu = std::max(1, std::atoi(e));   // experiments only
+        if (ctx->knobs.wg_per_cu > 0) per_cu = ctx->knobs.wg_per_cu;   // experiments only
         grid = (uint32_t)std::min<uint64_t>(tl.size(), (uint64_t)ctx->num_cu * per_cu);
         return PWA_OK;
     }
@@ -411,12 +463,12 @@ struct PairLaunch {
     int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, int walk, hipEvent_t after_fill, bool sband = false) {
         HIPC(ctx, hipMemsetAsync(p_queue, 0, 16, st));
         HIPC(ctx, hipMemsetAsync(p_progress, 0, progress_bytes, st));
-        if (std::getenv("PWA_STAMPS")) {
+        if (!ctx->knobs.stamps.empty()) {
             HIPC(ctx, stamps.alloc(n_stripes * 32 + 4 * 8192 * 8));
             HIPC(ctx, hipMemsetAsync(stamps.p, 0, n_stripes * 32 + 4 * 8192 * 8, st));
             G.stamps = stamps.as<unsigned long long>();
             G.trace_base = (uint32_t)(n_stripes * 4);
-            if (const char* e = std::getenv("PWA_TRACE_STRIPE")) G.trace_stripe = std::atoi(e);
+            G.trace_stripe = ctx->knobs.trace_stripe;
         }
         const pair_kernel_t fill = pair_fill_fn(geom, local, tb, sband, perm && tb && keyed, keyed, gap0 && tb && keyed && perm && !sband && !local);
         if (!fill) return fail(ctx, PWA_E_INVALID, "internal: no fill kernel for this geometry");
@@ -424,7 +476,7 @@ struct PairLaunch {
         // fits a CU: a stripe is one wave alone on its SIMD, and every stripe of a pair moves at the pace of the slowest --
         // two workgroups sharing a CU's four SIMDs would slow the whole pipeline
         size_t pad_lds = 0;
-        if (geom.w > 1 && grid <= (uint32_t)ctx->num_cu && !std::getenv("PWA_NO_LDS_PAD")) pad_lds = 96 * 1024;   // static (<= 16 KiB) + 96 KiB > half of the CU's 160 KiB
+        if (geom.w > 1 && grid <= (uint32_t)ctx->num_cu && !ctx->knobs.no_lds_pad) pad_lds = 96 * 1024;   // static (<= 16 KiB) + 96 KiB > half of the CU's 160 KiB
         if (pad_lds) HIPC(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds));
         hipLaunchKernelGGL(fill, dim3(grid), dim3(64 * (geom.w + 1)), pad_lds, st, G);
         HIPC(ctx, hipGetLastError());
@@ -435,7 +487,7 @@ struct PairLaunch {
     }
     // after the stream has been synchronised: did a bounded spin give up?
     int check(pwa_ctx* ctx) {
-        if (const char* path = std::getenv("PWA_STAMPS"); path && stamps.p) {
+        if (const char* path = ctx->knobs.stamps.c_str(); !ctx->knobs.stamps.empty() && stamps.p) {
             std::vector<unsigned long long> h(n_stripes * 4);
             HIPC(ctx, hipMemcpy(h.data(), stamps.p, n_stripes * 32, hipMemcpyDeviceToHost));
             if (FILE* f = std::fopen(path, "w")) {
@@ -521,6 +573,7 @@ int pwa_ctx_create(int device, pwa_ctx** out) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PWA_E_NODEVICE;   // kernels exist for gfx950 only
     pwa_ctx* c = new (std::nothrow) pwa_ctx();
     if (!c) return PWA_E_NOMEM;
+    c->knobs.read();   // the only place the library's switches are read from the environment
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -583,14 +636,14 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
     for (uint32_t s = 0; s < n_seq; ++s)
         if (seq_off[s + 1] < seq_off[s]) return fail(ctx, PWA_E_INVALID, "seq_off not monotone");
     HIPC(ctx, hipSetDevice(ctx->device));
-    const bool dbg = std::getenv("PWA_DEBUG") != nullptr;
+    const bool dbg = ctx->knobs.debug;
     auto t_last = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {   // PWA_DEBUG: host-side time between marks
         if (!dbg) return;
         const auto now = std::chrono::steady_clock::now();
         std::fprintf(stderr, "[pwa] create: %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
-        if (std::getenv("PWA_PROBE")) {   // how long does a kernel submission take at this point?
+        if (ctx->knobs.probe) {   // how long does a kernel submission take at this point?
             hipLaunchKernelGGL(pwa_nop_kernel, dim3(1), dim3(64), 0, ctx->stream, (int*)nullptr);
             (void)hipStreamSynchronize(ctx->stream);
             const auto t2 = std::chrono::steady_clock::now();
@@ -735,7 +788,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         // packed (H, dist) keys: dist in 12 bits, H in the 18 above (batch_nwdist.hip.h)
         const int64_t amax = std::max<int64_t>({std::llabs((long long)match), std::llabs((long long)mismatch),
                                                 std::llabs((long long)gap)});
-        if (max_n + max_m <= 4000 && (int64_t)(max_n + max_m + 2) * amax < 65536 && !std::getenv("PWA_NO_PACKED_DIST")) {
+        if (max_n + max_m <= 4000 && (int64_t)(max_n + max_m + 2) * amax < 65536 && !ctx->knobs.no_packed_dist) {
             kmode = BM_DISTP;
             tab_match = match;       // the packed kernel takes hw4's own three scores
             tab_mismatch = mismatch;
@@ -804,7 +857,10 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
                 lmin = std::min(lmin, l);
                 lmax = std::max(lmax, l);
             }
-            if (lmax - lmin < (1u << 22) && n_seq <= (1u << 24)) {
+            // (the histograms have n_seq + 1 and lmax - lmin + 1 entries whatever the list's size: a short list over a large
+            // FASTA index, or with one outlier length, is cheaper through the radix sort)
+            if (lmax - lmin < (1u << 22) && n_seq <= (1u << 24) && (uint64_t)n_seq <= 4 * (uint64_t)order.size() + 65536 &&
+                lmax - lmin <= 4 * (uint64_t)order.size() + 65536) {
                 std::vector<uint32_t> tmp;
                 if (lmax != lmin) counting_sort(order, tmp, (size_t)(lmax - lmin + 1), [&](uint32_t k) { return (size_t)(lmax - slen(pair_a[k])); });
                 counting_sort(order, tmp, (size_t)n_seq, [&](uint32_t k) { return (size_t)pair_b[k]; });
@@ -838,7 +894,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         const bool text_pad_ok = score_path == SC_PERM ? n_alpha <= 6 : text_pad_byte >= 0;
         const bool underfilled = ht.size() * 64 > order.size() * 3 / 2 + 64;
         b->lanes = kmode == BM_SW && !affine && !nwdist && kernels_have_lanes && text_pad_ok && underfilled &&
-                   !std::getenv("PWA_PAIRED");   // (the opt-in experiment wins)
+                   ctx->knobs.paired < 0;   // (the opt-in experiment wins)
         // global alignment: right-aligned texts, front-padded with a code the table scores like a gap (batch_scores.hip.h).
         // Needs the gap-shifted form, a coded alphabet with codes 4..7 free, every pattern symbol inside it (a
         // pattern-only symbol shares code 7 with the pad rows), g <= 0 and -g in a table byte.
@@ -847,7 +903,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         const bool lanes_nw = kmode == BM_NWG && !affine && !nwdist && score_path == SC_PERM && n_alpha <= 4 && patterns_inside &&
                               gap <= 0 && fits8(-gap) && underfilled;
         b->lanes = b->lanes || lanes_nw;
-        if (const char* e = std::getenv("PWA_FORCE_LANES")) b->lanes = b->lanes && std::atoi(e) != 0;   // experiments only
+        if (ctx->knobs.force_lanes >= 0) b->lanes = b->lanes && ctx->knobs.force_lanes != 0;   // experiments only
         if (b->lanes) {
             order = live;
             std::vector<uint64_t> key(order.size());   // nominal strips descending, then text length descending
@@ -871,8 +927,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         // ---- strip height: least padded work, ties to the taller strip
         int bestR = 0, best_mode = kmode;
         long double best_cost = -1;
-        const char* force = std::getenv("PWA_FORCE_R");      // experiments only
-        const char* force_mode = std::getenv("PWA_FORCE_MODE");
+        const int force = ctx->knobs.force_r, force_mode = ctx->knobs.force_mode;   // experiments only
         for (size_t ki = 0; ki < n_kernels; ++ki) {
             const BatchKernelEntry& e = kernels[ki];
             // SW has two forms: BM_SW (R registers per lane, 5.0 VALU per cell) and BM_SWS (2R registers, 4.06)
@@ -880,8 +935,8 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             if (!mode_ok || e.score != score_path) continue;
             if (b->lanes && !e.fn_lanes) continue;
             const int R = e.R;
-            if (force && std::atoi(force) != R) continue;
-            if (force_mode && std::atoi(force_mode) != e.mode) continue;
+            if (force && force != R) continue;
+            if (force_mode >= 0 && force_mode != e.mode) continue;
             long double w = e.mode == BM_SWS ? 4.06L : (e.mode == BM_SW ? 5.02L : 1.0L);   // VALU per cell
             // affine strips of more than 40 rows run 2 instead of 3 waves per SIMD: [gpu] all pairs of 1024 x 1000 take
             // 93.2 ms at R = 52 against 89.2 ms at R = 32 for the same padded cells
@@ -959,7 +1014,8 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
                 tbase[t] = total;
                 total += 64ull * ((ht[t].m + 3) / 4 * 4);
             }
-            if (total + 64 >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "per-lane text rows exceed 4 GiB");
+            if (total + 64 >= (ctx->knobs.lane_rows_limit ? ctx->knobs.lane_rows_limit : 0xffffffffull))
+                return fail(ctx, PWA_E_CAPACITY, "per-lane text rows exceed 4 GiB");   // (one-shot calls halve the run and retry)
             std::unique_ptr<uint8_t[]> rows(new uint8_t[total + 64]);
             std::memset(rows.get(), 4, total + 64);
             for (size_t t = 0; t < nt; ++t) {
@@ -999,8 +1055,8 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         // (84 GB per C3 launch -> none) but couples the two waves' progress: [gpu] 172.5 ms against 161.9 ms for the
         // HBM hand-off form, which already runs at the VALU issue limit -- hence not the default.
         b->paired = false;
-        if (const char* e = std::getenv("PWA_PAIRED"))
-            b->paired = std::atoi(e) != 0 && !affine && !nwdist && max_strips == 2 && b->kern->fn_pair != nullptr &&
+        if (ctx->knobs.paired >= 0)
+            b->paired = ctx->knobs.paired != 0 && !affine && !nwdist && max_strips == 2 && b->kern->fn_pair != nullptr &&
                         two_strip_tasks * 8 >= nt * 7;   // at most 1 task in 8 may leave the second wave idle
         if (b->lanes) {
             b->paired = false;
@@ -1076,7 +1132,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         b->live_idx = live;
         b->padded_cells = 0;
         std::vector<PairDesc> pd(nl);
-        const PairGeom geom = choose_geom(max_n);
+        const PairGeom geom = choose_geom(ctx->knobs, max_n);
         HIPC(ctx, b->pair_res.alloc(nl * sizeof(PairResult)));
         HIPC(ctx, hipMemset(b->pair_res.p, 0, nl * sizeof(PairResult)));
         for (size_t q = 0; q < nl; ++q) {
@@ -1352,7 +1408,10 @@ int pwa_batch_run(pwa_batch* b, void* stream_v) {
     HIPC(ctx, hipSetDevice(ctx->device));   // the caller's thread may have another device current
     hipStream_t st = stream_v ? static_cast<hipStream_t>(stream_v) : ctx->stream;
     const int slot = (int)(b->n_runs % pwa_batch::kRing);
-    if (!b->ev0[slot]) {
+    if (!b->ev0[slot] || !b->ev1[slot]) {   // both or neither: a half-created pair is torn down and created again
+        if (b->ev0[slot]) (void)hipEventDestroy(b->ev0[slot]);
+        if (b->ev1[slot]) (void)hipEventDestroy(b->ev1[slot]);
+        b->ev0[slot] = b->ev1[slot] = nullptr;
         HIPC(ctx, hipEventCreate(&b->ev0[slot]));
         HIPC(ctx, hipEventCreate(&b->ev1[slot]));
     }
@@ -1508,15 +1567,15 @@ void pwa_batch_destroy(pwa_batch* b) {
 // The strip engine addresses its sequence arena with 32-bit offsets (4 GiB per batch object).  The one-shot entry points
 // take pair lists of any size: the list is cut into runs of consecutive pairs whose sequences fit one arena, each run is
 // one batch object, results land in the caller's vectors at the run's offset (pairs are independent, hw2.cpp:328-338).
-static uint64_t arena_limit() {
-    if (const char* e = std::getenv("PWA_ARENA_LIMIT")) return std::max<uint64_t>(1024, std::strtoull(e, nullptr, 10));   // tests
+static uint64_t arena_limit(const pwa_ctx* ctx) {
+    if (ctx->knobs.arena_limit) return ctx->knobs.arena_limit;   // tests
     return 0xffffffffull - (1ull << 20);
 }
 template <class Create>
 static int scores_in_arena_chunks(pwa_ctx* ctx, const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
                                   uint64_t n_pairs, int32_t* score_out, uint32_t* end_i_out, uint32_t* end_j_out, Create&& create) try {
     if (!seq_off || (n_pairs && (!pair_a || !pair_b))) return fail(ctx, PWA_E_INVALID, "null input");
-    const uint64_t limit = arena_limit();
+    const uint64_t limit = arena_limit(ctx);
     std::vector<uint64_t> stamp(n_seq, 0);
     uint64_t k0 = 0, chunk = 0;
     do {
@@ -1535,6 +1594,12 @@ static int scores_in_arena_chunks(pwa_ctx* ctx, const uint64_t* seq_off, uint32_
         }
         pwa_batch* b = nullptr;
         int rc = create(pair_a + k0, pair_b + k0, k1 - k0, &b);
+        // the arena estimate above is not the only 32-bit limit inside a batch object (per-lane text rows of the LANES form, slot
+        // arrays): a run that is refused for its size is halved until it fits -- pairs are independent (hw2.cpp:328-338)
+        while (rc == PWA_E_CAPACITY && k1 - k0 > 1) {
+            k1 = k0 + (k1 - k0) / 2;
+            rc = create(pair_a + k0, pair_b + k0, k1 - k0, &b);
+        }
         if (rc != PWA_OK) return rc;
         rc = pwa_batch_run(b, nullptr);
         if (rc == PWA_OK) rc = pwa_batch_fetch(b, score_out + k0, end_i_out ? end_i_out + k0 : nullptr, end_j_out ? end_j_out + k0 : nullptr);
@@ -1601,7 +1666,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     auto slen = [&](uint32_t s) -> uint64_t { return seq_off[s + 1] - seq_off[s]; };
     ctx->fill_ms = ctx->tb_ms = 0.f;
     ctx->band_bytes = 0;
-    const bool dbg = std::getenv("PWA_DEBUG") != nullptr;
+    const bool dbg = ctx->knobs.debug;
     auto t_last = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {   // PWA_DEBUG: host-side time between marks
         if (!dbg) return;
@@ -1647,7 +1712,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         }
         const int64_t kd_match = ((int64_t)match - gap) * 4 + 2, kd_mismatch = ((int64_t)mismatch - gap) * 4 + 2;
         coded = n_alpha <= 7 && kd_match <= 127 && kd_match >= -126 && kd_mismatch <= 127 && kd_mismatch >= -126 &&
-                !std::getenv("PWA_NO_PAIR_TABLE");
+                !ctx->knobs.no_pair_table;
         dash_seen = seen[(unsigned char)'-'];
     }
     // overlapLongestExactMatch (hw2.cpp:269) does not count a column whose symbols are '-' -- also when the '-' is part
@@ -1668,19 +1733,19 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         longest_sum = std::max(longest_sum, slen(pair_a[k]) + slen(pair_b[k]));
     }
     // scores x lengths beyond the packed keys' 2^28: the plain int32 form, exact for anything the reference's int holds
-    const bool keyed = tb_range_ok(longest_sum, match, mismatch, gap) && !std::getenv("PWA_NO_KEYED_TB");
+    const bool keyed = tb_range_ok(longest_sum, match, mismatch, gap) && !ctx->knobs.no_keyed_tb;
     // Global alignments with table scoring run in gap-shifted coordinates G = H - gap (i + j): the same recurrence with gap 0 and
     // scores s - 2 gap, identical comparisons and codes, one instruction less per cell (pair_fill.hip.h, GAP0).  |G| <= |H| +
     // |gap| (n + m): twice the range; both shifted diagonal constants must fit the byte table.
     bool gap0 = false;
-    if (!local && coded && keyed && !ctx->score_band && !std::getenv("PWA_NO_GAP_SHIFT")) {
+    if (!local && coded && keyed && !ctx->score_band && !ctx->knobs.no_gap_shift) {
         const int64_t sm = (int64_t)match - 2 * (int64_t)gap, sx = (int64_t)mismatch - 2 * (int64_t)gap;
         const int64_t km = sm * 4 + 1, kx = sx * 4 + 1;   // (s' - 0) * 4 + prio(diag) - prio(left)
         const int64_t amax = std::max<int64_t>({std::llabs((long long)match), std::llabs((long long)mismatch), std::llabs((long long)gap), 1});
         gap0 = km <= 127 && km >= -126 && kx <= 127 && kx >= -126 && (longest_sum + 2) <= (1ull << 27) / (uint64_t)amax;
     }
     const int k_match = gap0 ? match - 2 * gap : match, k_mismatch = gap0 ? mismatch - 2 * gap : mismatch, k_gap = gap0 ? 0 : gap;
-    const PairGeom geom = choose_geom(longest_n, keyed, true);
+    const PairGeom geom = choose_geom(ctx->knobs, longest_n, keyed, true);
     auto tb_band_bytes = [&](uint64_t n, uint64_t m) { return ::tb_band_bytes(n, m, geom.rl); };
     // pairs are processed in chunks whose traceback bands fit the free HBM
     size_t free_b = 0, total_b = 0;
@@ -1720,7 +1785,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
                 if (k + 1 < k1 && ops_off[k + 1] != ops_off[k] + cap) tiled = false;
                 span += cap;
             }
-            if (std::getenv("PWA_NO_TILED_OPS")) tiled = false;
+            if (ctx->knobs.no_tiled_ops) tiled = false;
         }
         chunks.push_back({k0, k1, band, opsb, tiled, span});
         band_cap = std::max(band_cap, band);
@@ -1898,7 +1963,7 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     if (mode != PWA_MODE_NW && mode != PWA_MODE_SW) return fail(ctx, PWA_E_INVALID, "unknown mode");
     if ((n && !pattern) || (m && !text) || (!dp_out && !tb_out)) return fail(ctx, PWA_E_INVALID, "null input");
     if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
-    const bool keyed = tb_range_ok(n + m, match, mismatch, gap) && !std::getenv("PWA_NO_KEYED_TB");
+    const bool keyed = tb_range_ok(n + m, match, mismatch, gap) && !ctx->knobs.no_keyed_tb;
     const bool local = mode == PWA_MODE_SW;
     const uint64_t W = m + 1;
     // row 0 and column 0 exactly as the reference initialises them (hw2.cpp:119-136 / 193-194)
@@ -1912,7 +1977,7 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     }
     if (n == 0 || m == 0) return PWA_OK;
     HIPC(ctx, hipSetDevice(ctx->device));
-    const PairGeom geom = choose_geom(n, keyed, true);
+    const PairGeom geom = choose_geom(ctx->knobs, n, keyed, true);
     const uint64_t kRL = (uint64_t)geom.rl;
     const uint64_t band = tb_band_bytes(n, m, geom.rl);
     DevBuf d_pat, d_txt, d_band, d_sband, d_res;

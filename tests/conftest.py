@@ -1,3 +1,4 @@
+import contextlib
 import json
 import os
 import sys
@@ -56,6 +57,31 @@ def load_pkg():
 @pytest.fixture(scope="session")
 def pkg():
     return load_pkg()
+
+
+
+
+
+@contextlib.contextmanager
+def switched_context(**env):
+    """The library reads its PWA_* test / diagnostic switches ONCE, in pwa_ctx_create (include/pwalign.h): a test that
+    wants one set creates its own context with it in the environment -- and takes it out again right away, which is also
+    the check that no entry point consults the environment later."""
+    pkg = load_pkg()
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        c = pkg.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        yield c
+    finally:
+        c.close()
 
 
 @pytest.fixture(scope="session")

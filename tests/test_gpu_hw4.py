@@ -6,7 +6,7 @@ import subprocess
 import pytest
 
 import oracle_lib as O
-from conftest import B, GOLDEN, load_golden
+from conftest import B, GOLDEN, load_golden, switched_context
 
 SCORINGS = [(1, -1, -1), (2, -3, -5), (5, -4, -4), (1, -3, -1), (1, 1, 1), (0, 0, 0), (-1, 2, 1), (1, -1, 0), (100, -90, -70)]
 
@@ -45,22 +45,21 @@ def test_distance_reference_fixtures(ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("packed", [True, False])
 @pytest.mark.parametrize("alphabet", [b"ACGT", b"AC", bytes(range(65, 91)), bytes(range(1, 256))])
-def test_distance_random_batches_match_oracle(ctx, alphabet, packed, monkeypatch):
+def test_distance_random_batches_match_oracle(alphabet, packed):
     """both forms of the kernel: (H, dist) packed into one int32 key (the default while dist < 2^12 and H fits 18 bits;
     the scoring 100/-90/-70 does not and takes the plain form by itself) and the plain two-value form (forced)."""
-    if not packed:
-        monkeypatch.setenv("PWA_NO_PACKED_DIST", "1")
     rng = random.Random(len(alphabet) + 7)
     lens = [0, 1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, 300]
     seqs = [bytes(rng.choice(alphabet) for _ in range(rng.choice(lens) if rng.random() < 0.5 else rng.randint(1, 260)))
             for _ in range(60)]
     pa = [rng.randrange(60) for _ in range(500)]
     pb = [rng.randrange(12) if rng.random() < 0.8 else rng.randrange(60) for _ in range(500)]
-    for sc in SCORINGS:
-        got = ctx.distances(seqs, pa, pb, *sc)
-        want = [O.nw_distance(seqs[a], seqs[b], *sc)[0] for a, b in zip(pa, pb)]
-        bad = [k for k in range(500) if got[k] != want[k]]
-        assert not bad, (sc, [(len(seqs[pa[k]]), len(seqs[pb[k]]), got[k], want[k]) for k in bad[:5]])
+    with switched_context(**({} if packed else {"PWA_NO_PACKED_DIST": "1"})) as ctx:
+        for sc in SCORINGS:
+            got = ctx.distances(seqs, pa, pb, *sc)
+            want = [O.nw_distance(seqs[a], seqs[b], *sc)[0] for a, b in zip(pa, pb)]
+            bad = [k for k in range(500) if got[k] != want[k]]
+            assert not bad, (sc, [(len(seqs[pa[k]]), len(seqs[pb[k]]), got[k], want[k]) for k in bad[:5]])
 
 
 @pytest.mark.gpu

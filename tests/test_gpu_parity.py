@@ -9,7 +9,7 @@ import subprocess
 import pytest
 
 import oracle_lib as O
-from conftest import B, GOLDEN, load_golden
+from conftest import B, GOLDEN, load_golden, switched_context
 
 pytestmark = pytest.mark.gpu
 
@@ -71,24 +71,23 @@ def test_align_kats_long_pairs(ctx):
 
 
 @pytest.mark.parametrize("alphabet,table", [(b"ACGT", True), (b"ACGT", False), (b"ACGTNRY", True), (b"ACDEFGHIKLMNPQRSTVWY", True)])
-def test_align_batch_matches_oracle(ctx, alphabet, table, monkeypatch):
+def test_align_batch_matches_oracle(alphabet, table):
     """both scoring forms of the traceback fill: byte-table lookups on coded sequences (alphabets of <= 7 symbols) and
     compare + select on raw bytes (larger alphabets, or forced)."""
-    if not table:
-        monkeypatch.setenv("PWA_NO_PAIR_TABLE", "1")
     rng = random.Random(5)
     seqs = [bytes(rng.choice(alphabet) for _ in range(rng.randint(0, 400))) for _ in range(40)]
     pa = [rng.randrange(40) for _ in range(100)]
     pb = [rng.randrange(40) for _ in range(100)]
-    for mode in ("nw", "sw"):
-        for sc in [(1, -1, -1), (2, -3, -5), (20, -15, -9), (40, -3, 2)]:   # the last two leave the byte table's range
-            res = ctx.align_batch(mode, seqs, pa, pb, *sc)
-            for k, r in enumerate(res):
-                want = O.align(mode, seqs[pa[k]], seqs[pb[k]], *sc)
-                assert r["score"] == want["score"], (mode, k)
-                assert r["ops"] == want["ops"], (mode, k)
-                assert tuple(r["end"]) == tuple(want["end"])
-                assert tuple(r["start"]) == tuple(want["start"])
+    with switched_context(**({} if table else {"PWA_NO_PAIR_TABLE": "1"})) as c:
+        for mode in ("nw", "sw"):
+            for sc in [(1, -1, -1), (2, -3, -5), (20, -15, -9), (40, -3, 2)]:   # the last two leave the byte table's range
+                res = c.align_batch(mode, seqs, pa, pb, *sc)
+                for k, r in enumerate(res):
+                    want = O.align(mode, seqs[pa[k]], seqs[pb[k]], *sc)
+                    assert r["score"] == want["score"], (mode, k)
+                    assert r["ops"] == want["ops"], (mode, k)
+                    assert tuple(r["end"]) == tuple(want["end"])
+                    assert tuple(r["start"]) == tuple(want["start"])
 
 
 def test_align_batch_with_score_band_matches_oracle(ctx):
@@ -162,19 +161,15 @@ def test_device_overlaps_with_dash_symbols_match_reference(ctx):
     for rec in recs:
         groups.setdefault((rec["mode"], tuple(rec["scoring"])), []).append(rec)
     for raw in (False, True):
-        if raw:
-            os.environ["PWA_NO_PAIR_TABLE"] = "1"
-        try:
+        with switched_context(**({"PWA_NO_PAIR_TABLE": "1"} if raw else {})) as c:
             for (mode, sc), rs in groups.items():
                 seqs = [B(r["p"]) for r in rs] + [B(r["t"]) for r in rs]
                 pa = list(range(len(rs)))
                 pb = [len(rs) + k for k in range(len(rs))]
-                scores, ovl = ctx.overlaps(mode, seqs, pa, pb, *sc)
+                scores, ovl = c.overlaps(mode, seqs, pa, pb, *sc)
                 for k, r in enumerate(rs):
                     assert scores[k] == r["score"], (mode, sc, k)
                     assert ovl[k] == r["overlap"], (mode, sc, r["p"], r["t"], ovl[k], r["overlap"])
-        finally:
-            os.environ.pop("PWA_NO_PAIR_TABLE", None)
     # the case of VERDICT r01: the winner of -g changes (pair 2, overlap 4; pair 1's run is cut at the '-': 2)
     scores, ovl = ctx.overlaps("nw", [b"AC-GT", b"ACGA"], [0, 1], [0, 1], 1, -1, -1)
     assert (scores, ovl) == ([5, 4], [2, 4])
@@ -280,16 +275,13 @@ def test_two_strip_tasks_through_the_lds_paired_kernel(ctx):
                 if (i >= 90) == short_text and rng.random() < 0.9:
                     pa.append(i)
                     pb.append(len(pats) + j)
-        os.environ["PWA_PAIRED"] = "1"   # opt-in form (read at batch creation)
-        try:
-            b = ctx.batch("sw", seqs, pa, pb, *scoring)
-        finally:
-            del os.environ["PWA_PAIRED"]
-        assert "pair_kernel" in b.info()["kernel"], b.info()
-        for _ in range(2):
-            b.run()
-            got = b.fetch()
-        b.close()
+        with switched_context(PWA_PAIRED="1") as c:   # opt-in form (a switch of the context)
+            b = c.batch("sw", seqs, pa, pb, *scoring)
+            assert "pair_kernel" in b.info()["kernel"], b.info()
+            for _ in range(2):
+                b.run()
+                got = b.fetch()
+            b.close()
         want = [O.score("sw", seqs[a], seqs[c], *scoring)[0] for a, c in zip(pa, pb)]
         bad = [k for k in range(len(pa)) if got[k] != want[k]]
         assert not bad, (scoring, bad[:5], [(len(seqs[pa[k]]), len(seqs[pb[k]]), got[k], want[k]) for k in bad[:5]])
@@ -786,15 +778,15 @@ def test_scores_beyond_the_packed_key_range_match_reference(ctx):
 
 
 @pytest.mark.parametrize("name", ["bundled", "edge", "dash"])
-def test_plain_int32_traceback_form_on_the_reference_fixtures(ctx, name, monkeypatch):
+def test_plain_int32_traceback_form_on_the_reference_fixtures(name):
     """the same fixtures as test_align_matches_reference_fixtures through the plain int32 traceback form (forced)"""
-    monkeypatch.setenv("PWA_NO_KEYED_TB", "1")
-    for rec in load_golden(name):
-        got = ctx.align(rec["mode"], B(rec["p"]), B(rec["t"]), *rec["scoring"])
-        check_alignment(got, rec)
+    with switched_context(PWA_NO_KEYED_TB="1") as c:
+        for rec in load_golden(name):
+            got = c.align(rec["mode"], B(rec["p"]), B(rec["t"]), *rec["scoring"])
+            check_alignment(got, rec)
 
 
-def test_one_shot_calls_cut_oversized_pair_lists_into_arena_chunks(ctx, monkeypatch):
+def test_one_shot_calls_cut_oversized_pair_lists_into_arena_chunks(ctx):
     """pwa_scores / pwa_distances / pwa_scores_affine on pair lists whose sequences exceed one 4 GiB arena: the list is
     processed in runs of pairs that fit (limit lowered to 6 KiB here so that ~30 chunks form, incl. sequences reused
     across chunks and a pair of one sequence with itself)."""
@@ -806,17 +798,17 @@ def test_one_shot_calls_cut_oversized_pair_lists_into_arena_chunks(ctx, monkeypa
     whole_end = ctx.scores("sw", seqs, pa, pb, 2, -3, -5, want_end=True)
     whole_d = ctx.distances(seqs, pa, pb, 1, -1, -1)
     whole_a = ctx.scores_affine_oneshot(seqs, pa, pb, 5, -4, -16, -4)
-    monkeypatch.setenv("PWA_ARENA_LIMIT", "6144")
-    for m in ("nw", "sw"):
-        got = ctx.scores(m, seqs, pa, pb, 2, -3, -5)
-        assert got == whole[m] == [O.score(m, seqs[a], seqs[b], 2, -3, -5)[0] for a, b in zip(pa, pb)]
-    assert ctx.scores("sw", seqs, pa, pb, 2, -3, -5, want_end=True) == whole_end
-    assert ctx.distances_oneshot(seqs, pa, pb, 1, -1, -1) == whole_d == [O.nw_distance(seqs[a], seqs[b], 1, -1, -1)[0] for a, b in zip(pa, pb)]
-    assert ctx.scores_affine_oneshot(seqs, pa, pb, 5, -4, -16, -4) == whole_a == [O.affine_score(seqs[a], seqs[b], 5, -4, -16, -4) for a, b in zip(pa, pb)]
+    with switched_context(PWA_ARENA_LIMIT="6144") as c:
+        for m in ("nw", "sw"):
+            got = c.scores(m, seqs, pa, pb, 2, -3, -5)
+            assert got == whole[m] == [O.score(m, seqs[a], seqs[b], 2, -3, -5)[0] for a, b in zip(pa, pb)]
+        assert c.scores("sw", seqs, pa, pb, 2, -3, -5, want_end=True) == whole_end
+        assert c.distances_oneshot(seqs, pa, pb, 1, -1, -1) == whole_d == [O.nw_distance(seqs[a], seqs[b], 1, -1, -1)[0] for a, b in zip(pa, pb)]
+        assert c.scores_affine_oneshot(seqs, pa, pb, 5, -4, -16, -4) == whole_a == [O.affine_score(seqs[a], seqs[b], 5, -4, -16, -4) for a, b in zip(pa, pb)]
 
 
 @pytest.mark.parametrize("n_class", [(1, 63, 64), (65, 127, 128), (129, 200, 256), (257, 300, 511, 512, 513), (700, 1025, 1100, 1537)])
-def test_pair_engine_shapes_around_every_boundary(ctx, n_class, monkeypatch):
+def test_pair_engine_shapes_around_every_boundary(n_class):
     """The written-out fill chunks (r02): pattern lengths around stripe / workgroup boundaries x text lengths around hand-off chunks
     (16 steps), the lane ramp (63 steps) and the LDS ring (512 columns), for both modes, table and compare scoring, gap-shifted and
     plain global form, with and without the score band -- every op list, end and start cell against the oracle.  All pairs of one
@@ -834,21 +826,15 @@ def test_pair_engine_shapes_around_every_boundary(ctx, n_class, monkeypatch):
             pb.append(len(seqs) - 1)
     variants = [({}, False), ({"PWA_NO_GAP_SHIFT": "1"}, False), ({"PWA_NO_PAIR_TABLE": "1"}, False), ({}, True)]
     for env, band in variants:
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        ctx.set_score_band(band)
-        try:
+        with switched_context(**env) as c:
+            c.set_score_band(band)
             for mode in ("nw", "sw"):
                 for sc in [(1, -1, -1), (2, -3, -5)]:
-                    res = ctx.align_batch(mode, seqs, pa, pb, *sc)
+                    res = c.align_batch(mode, seqs, pa, pb, *sc)
                     for k, r in enumerate(res):
                         want = O.align(mode, seqs[pa[k]], seqs[pb[k]], *sc, compact=True)
                         assert (r["score"], r["ops"], tuple(r["end"]), tuple(r["start"])) == \
                             (want["score"], want["ops"], tuple(want["end"]), tuple(want["start"])), (env, band, mode, sc, len(seqs[pa[k]]), len(seqs[pb[k]]))
-        finally:
-            ctx.set_score_band(False)
-            for k in env:
-                monkeypatch.delenv(k, raising=False)
 
 
 def _indel_blocks(rng, s, n_events, max_len):
@@ -865,12 +851,10 @@ def _indel_blocks(rng, s, n_events, max_len):
 
 
 @pytest.mark.parametrize("force_rl", [None, "4", "2"])
-def test_walk_across_gap_runs_drift_and_ties(ctx, force_rl, monkeypatch):
+def test_walk_across_gap_runs_drift_and_ties(force_rl):
     """The op-list walk (r02) follows the path over seven diagonals per LDS round trip and ends a trip when the path drifts off them,
     leaves the staged windows or the stripe: paths with long runs of gaps in one direction, zig-zags of single gaps, tie-riddled
     homopolymers and scorings that prefer gaps, over one- and many-stripe patterns -- every op list against the oracle."""
-    if force_rl:
-        monkeypatch.setenv("PWA_FORCE_RL", force_rl)
     rng = random.Random(77)
     seqs, pa, pb = [], [], []
 
@@ -896,16 +880,14 @@ def test_walk_across_gap_runs_drift_and_ties(ctx, force_rl, monkeypatch):
         add(b"A" * n, b"A" * (n + 37))                       # ties everywhere: the reference's order of preference decides
         add(b"AC" * (n // 2), b"CA" * (n // 2 + 11))
         add(base, bytes(rng.choice(b"ACGT") for _ in range(n // 2 + 5)))
-    try:
+    with switched_context(**({"PWA_FORCE_RL": force_rl} if force_rl else {})) as c:
         for mode in ("nw", "sw"):
             for sc in [(1, -1, -1), (1, -3, -1), (2, -1, -3), (0, 0, 0), (1, 1, 1), (-1, 2, 1), (1, -1, 0)]:
-                res = ctx.align_batch(mode, seqs, pa, pb, *sc)
+                res = c.align_batch(mode, seqs, pa, pb, *sc)
                 for k, r in enumerate(res):
                     want = O.align(mode, seqs[pa[k]], seqs[pb[k]], *sc, compact=True)
                     assert (r["score"], r["ops"], tuple(r["end"]), tuple(r["start"])) == \
                         (want["score"], want["ops"], tuple(want["end"]), tuple(want["start"])), (force_rl, mode, sc, k, len(seqs[pa[k]]), len(seqs[pb[k]]))
-    finally:
-        monkeypatch.delenv("PWA_FORCE_RL", raising=False)
 
 
 def test_pipeline_handoff_under_uneven_concurrent_load(ctx):
