@@ -522,7 +522,8 @@ struct pwa_batch {
     uint64_t cells = 0, padded_cells = 0;
     bool want_end = false;
     // engine 1: register-strip kernels
-    bool use_strips = false;
+    bool use_strips = false;        // some pairs run on the register-strip kernels
+    bool use_pairs = false;         // some (or, with end cells / scorings the strips cannot pad for, all) pairs run on the stripe engine
     const BatchKernelEntry* kern = nullptr;
     BatchParams bp{};
     bool affine = false, nwdist = false, single_strip = false, paired = false, lanes = false;
@@ -844,6 +845,9 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
     }
 
     mark("validate + arena upload");
+    b->padded_cells = 0;
+    std::vector<uint32_t> live_pairs_engine;   // the pairs that run on the stripe engine (all of them when the strips cannot serve the list)
+    if (!b->use_strips) live_pairs_engine = live;
     if (b->use_strips) {
         // ---- wave tasks: pairs grouped by text, patterns sorted by length, 64 per wave
         std::vector<uint32_t> order(live);   // ascending pair index: the stable sorts below keep it as the last key
@@ -926,12 +930,16 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         mark("sort + group pairs");
         // ---- strip height: least padded work, ties to the taller strip
         int bestR = 0, best_mode = kmode;
+        const int kmode_asked = kmode;
+        auto choose_strip_height = [&]() {
+        bestR = 0;
+        best_mode = kmode_asked;
         long double best_cost = -1;
         const int force = ctx->knobs.force_r, force_mode = ctx->knobs.force_mode;   // experiments only
         for (size_t ki = 0; ki < n_kernels; ++ki) {
             const BatchKernelEntry& e = kernels[ki];
             // SW has two forms: BM_SW (R registers per lane, 5.0 VALU per cell) and BM_SWS (2R registers, 4.06)
-            const bool mode_ok = e.mode == kmode || (kmode == BM_SW && e.mode == BM_SWS);
+            const bool mode_ok = e.mode == kmode_asked || (kmode_asked == BM_SW && e.mode == BM_SWS);
             if (!mode_ok || e.score != score_path) continue;
             if (b->lanes && !e.fn_lanes) continue;
             const int R = e.R;
@@ -955,10 +963,97 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
                 best_mode = e.mode;
             }
         }
-        kmode = best_mode;
+        };
+        choose_strip_height();
         if (bestR == 0) return fail(ctx, PWA_E_INVALID, "internal: no kernel instantiation");
+
+        // ---- work-aware routing (r03).  The strip engine is the cheaper one per cell (lane = pair, 2.5 - 5 VALU per cell) but a wave
+        // task is one wave running strips x columns on its own: a list of few long pairs -- ONE 10k x 10k pair is 105 strips x 2500
+        // column blocks x 1560 instructions on one lane of one wave, [gpu] 779 ms against 1.67 ms on the stripe engine -- or of few
+        // wave tasks (4096 pairs 150 x 10k = 64 tasks: 11.6 ms against 4.3 ms) leaves the chip idle.  The stripe engine spreads a
+        // pair over ceil(n / (64 RL)) waves that sweep anti-diagonals (~100 ns per step of 64 RL cells per SIMD).  Both costs are
+        // estimated from the task list with constants measured on the GPU (profiles/r03_route_probe.txt), tasks are moved to the
+        // stripe engine in two candidate orders (largest strip task first; cheapest-to-move per unit of strip work first) and
+        // the split with the smallest estimated total -- the two launches run one after the other on the run's stream -- wins.
+        // Pairs are independent (hw2.cpp:328-338) and both engines are exact, so a split changes no result.
+        std::vector<uint32_t> pair_list;   // pair indices routed to the stripe engine
+        if (!affine && !nwdist && ctx->knobs.scores_route != 0) {
+            const size_t nt0 = ht.size();
+            const double vpc = (best_mode == BM_SWS ? 4.06 : best_mode == BM_SW ? 5.02 : best_mode == BM_NWG ? 2.53 : 4.5) + (score_path == SC_CMP ? 2.0 : 0.0);
+            constexpr double kLoneNs = 1.9, kSimdNs = 1.63, kSimds = 1024.0;                // ns per wave instruction: one wave alone / a SIMD with two
+            const double step_ns = local ? 105.0 : 75.0, lag_us = 9.0, lone_step_ns = 100.0;   // stripe engine: per step and SIMD; per stripe of pipeline lag
+            std::vector<double> I(nt0), S(nt0), L(nt0);   // strip instructions / stripe-engine steps / longest single-pair latency (us) of a task
+            double I_total = 0;
+            for (size_t t = 0; t < nt0; ++t) {
+                const uint64_t strips = (ht[t].maxlen + bestR - 1) / bestR;
+                I[t] = (double)strips * (double)((ht[t].m + 3) / 4) * (4.0 * bestR * vpc);
+                I_total += I[t];
+                double steps = 0, lat = 0;
+                for (uint32_t l = 0; l < ht[t].count; ++l) {
+                    const uint32_t k = order[ht[t].first + l];
+                    const uint64_t n = slen(pair_a[k]), m = slen(pair_b[k]);
+                    const PairGeom g = choose_geom(ctx->knobs, n);
+                    const double stripes = (double)((n + 64 * g.rl - 1) / (64 * g.rl));
+                    steps += stripes * (double)(m + 63);
+                    lat = std::max(lat, stripes * lag_us + (double)(m + 63) * lone_step_ns * 1e-3);
+                }
+                S[t] = steps;
+                L[t] = lat;
+            }
+            auto evaluate = [&](const std::vector<uint32_t>& ord, size_t& best_k) -> double {
+                // tasks ord[0 .. k-1] move; suffix maxima of I over the tasks that stay
+                std::vector<double> sufmax(nt0 + 1, 0.0);
+                for (size_t k = nt0; k-- > 0;) sufmax[k] = std::max(sufmax[k + 1], I[ord[k]]);
+                double best_t = -1, moved_I = 0, moved_S = 0, moved_L = 0;
+                for (size_t k = 0; k <= nt0; ++k) {
+                    const double ts = std::max(sufmax[k] * kLoneNs, (I_total - moved_I) / kSimds * kSimdNs) * 1e-3;              // us
+                    const double tp = k ? std::max(moved_L, moved_S / kSimds * step_ns * 1e-3) + 15.0 : 0.0;                       // us (+ two more launches)
+                    const double tt = ts + tp;
+                    if (best_t < 0 || tt < best_t) {
+                        best_t = tt;
+                        best_k = k;
+                    }
+                    if (k < nt0) {
+                        moved_I += I[ord[k]];
+                        moved_S += S[ord[k]];
+                        moved_L = std::max(moved_L, L[ord[k]]);
+                    }
+                }
+                return best_t;
+            };
+            std::vector<uint32_t> ordA(nt0), ordB(nt0);
+            std::iota(ordA.begin(), ordA.end(), 0u);
+            ordB = ordA;
+            std::stable_sort(ordA.begin(), ordA.end(), [&](uint32_t x, uint32_t y) { return I[x] > I[y]; });
+            std::stable_sort(ordB.begin(), ordB.end(), [&](uint32_t x, uint32_t y) { return S[x] * I[y] < S[y] * I[x]; });   // S / I ascending
+            size_t kA = 0, kB = 0;
+            const double tA = evaluate(ordA, kA), tB = evaluate(ordB, kB);
+            const std::vector<uint32_t>& ord = tA <= tB ? ordA : ordB;
+            size_t kmove = tA <= tB ? kA : kB;
+            if (ctx->knobs.scores_route == 1) kmove = nt0;   // tests: everything on the stripe engine
+            if (dbg) std::fprintf(stderr, "[pwa] route: %zu of %zu wave tasks to the stripe engine (estimates: all on strips %.1f us, split %.1f us)\n",
+                                  kmove, nt0, std::max(*std::max_element(I.begin(), I.end()) * kLoneNs, I_total / kSimds * kSimdNs) * 1e-3, std::min(tA, tB));
+            if (kmove) {
+                std::vector<uint8_t> moved(nt0, 0);
+                for (size_t k = 0; k < kmove; ++k) moved[ord[k]] = 1;
+                std::vector<HostTask> keep;
+                for (size_t t = 0; t < nt0; ++t) {
+                    if (!moved[t]) {
+                        keep.push_back(ht[t]);
+                        continue;
+                    }
+                    for (uint32_t l = 0; l < ht[t].count; ++l) pair_list.push_back(order[ht[t].first + l]);
+                }
+                ht.swap(keep);
+                std::sort(pair_list.begin(), pair_list.end());
+                if (!ht.empty()) choose_strip_height();   // the strips that stay may prefer another height
+            }
+        }
+        if (ht.empty()) b->use_strips = false;
+        live_pairs_engine.swap(pair_list);
+      if (b->use_strips) {
+        kmode = best_mode;
         const int R = bestR;
-        b->padded_cells = 0;
         for (const auto& t : ht) b->padded_cells += (t.maxlen + bestR - 1) / bestR * bestR * (b->lanes ? (t.m + 3) / 4 * 4 : t.m) * 64;
         b->kern = find_batch_kernel(R, kmode, score_path);
         if (!b->kern) return fail(ctx, PWA_E_INVALID, "internal: no kernel instantiation");
@@ -1126,17 +1221,22 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         if (b->lanes && kmode == BM_NWG) P.tab_hi = (uint32_t)(uint8_t)(int8_t)(-gap) * 0x01010101u;   // selectors 4..7: front pad = a gap column
         P.slot_toff = b->slot_toff.as<uint32_t>();
         P.slot_tlen = b->slot_tlen.as<uint32_t>();
-    } else {
-        // ---- wavefront engine, no traceback band: exact first-maximum end cells, any scoring
-        const size_t nl = live.size();
-        b->live_idx = live;
-        b->padded_cells = 0;
+      }   // strips that stay
+    }
+    if (!live_pairs_engine.empty()) {
+        // ---- stripe engine, no traceback band: exact first-maximum end cells, any scoring
+        const std::vector<uint32_t>& plist = live_pairs_engine;
+        const size_t nl = plist.size();
+        b->use_pairs = true;
+        b->live_idx = plist;
         std::vector<PairDesc> pd(nl);
-        const PairGeom geom = choose_geom(ctx->knobs, max_n);
+        uint64_t pe_max_n = 0;
+        for (const uint32_t k : plist) pe_max_n = std::max(pe_max_n, slen(pair_a[k]));
+        const PairGeom geom = choose_geom(ctx->knobs, pe_max_n);
         HIPC(ctx, b->pair_res.alloc(nl * sizeof(PairResult)));
         HIPC(ctx, hipMemset(b->pair_res.p, 0, nl * sizeof(PairResult)));
         for (size_t q = 0; q < nl; ++q) {
-            const uint32_t k = live[q];
+            const uint32_t k = plist[q];
             std::memset(&pd[q], 0, sizeof(PairDesc));
             pd[q].pat = b->arena.as<uint8_t>() + aoff[pair_a[k]];
             pd[q].txt = b->arena.as<uint8_t>() + aoff[pair_b[k]];
@@ -1152,7 +1252,8 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             if (rc != PWA_OK) return rc;
             b->pl.G.scores_out = b->scores.as<int32_t>();   // the device score vector is complete after run()
         }
-        b->kernel_name = std::string("pair_fill_kernel<RL=") + std::to_string(geom.rl) + (local ? ",SW" : ",NW") + ",no-traceback>";
+        const std::string pname = std::string("pair_fill_kernel<RL=") + std::to_string(geom.rl) + (local ? ",SW" : ",NW") + ",no-traceback>";
+        b->kernel_name = b->use_strips ? b->kernel_name + " + " + pname : pname;   // (the strip kernel first: bench.py prices its instruction mix)
     }
     if (dbg) {
         mark("engine setup");
@@ -1439,7 +1540,8 @@ int pwa_batch_run(pwa_batch* b, void* stream_v) {
                 else hipLaunchKernelGGL(b->single_strip ? b->kern->fn_single : b->kern->fn, dim3(b->grid), dim3(64), 0, st, b->bp);
             }
             HIPC(ctx, hipGetLastError());
-        } else {
+        }
+        if (b->use_pairs) {
             const int rc = b->pl.launch(ctx, st, b->mode == PWA_MODE_SW, false, false, nullptr);
             if (rc != PWA_OK) return rc;
         }
@@ -1495,7 +1597,7 @@ int pwa_batch_info(const pwa_batch* b, uint64_t* cells, uint64_t* padded_cells, 
     if (!b) return PWA_E_INVALID;
     if (cells) *cells = b->cells;
     if (padded_cells) *padded_cells = b->padded_cells;
-    if (n_tasks) *n_tasks = b->use_strips ? b->bp.n_tasks : b->n_live;
+    if (n_tasks) *n_tasks = (b->use_strips ? b->bp.n_tasks : 0) + (b->use_pairs ? b->live_idx.size() : 0);
     if (kernel_name) *kernel_name = b->kernel_name.c_str();
     return PWA_OK;
 }
@@ -1507,7 +1609,11 @@ int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint3
     if (!b->ran) return fail(ctx, PWA_E_INVALID, "pwa_batch_run has not been called");
     HIPC(ctx, hipSetDevice(ctx->device));
     HIPC(ctx, hipEventSynchronize(b->ev1[(b->n_runs - 1) % pwa_batch::kRing]));
-    if (b->use_strips || b->n_live == 0) {
+    if (b->use_pairs) {   // the bounded spins of the stripe pipeline: a workgroup that gave up says so here
+        const int rc = b->pl.check(ctx);
+        if (rc != PWA_OK) return rc;
+    }
+    if (!b->want_end || b->n_live == 0) {   // both engines write their pairs' scores into the device score vector
         if (b->paired && b->n_live) {   // the LDS hand-off spins are bounded; a wave that gave up says so here
             uint32_t q[2] = {0, 0};
             HIPC(ctx, hipMemcpy(q, b->queue.p, sizeof q, hipMemcpyDeviceToHost));
@@ -1520,11 +1626,7 @@ int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint3
         }
         return PWA_OK;
     }
-    {
-        const int rc = b->pl.check(ctx);
-        if (rc != PWA_OK) return rc;
-    }
-    std::vector<PairResult> res(b->n_live);
+    std::vector<PairResult> res(b->n_live);   // end cells asked for: every live pair ran on the stripe engine
     HIPC(ctx, hipMemcpy(res.data(), b->pair_res.p, b->n_live * sizeof(PairResult), hipMemcpyDeviceToHost));
     std::memcpy(score_out, b->host_scores.data(), b->n_pairs * sizeof(int32_t));
     if (b->want_end) {

@@ -84,6 +84,22 @@ def switched_context(**env):
         c.close()
 
 
+@pytest.fixture(scope="session", params=["strips", "routed"])
+def sctx(request, pkg):
+    """Scores-only passes on both routes: "strips" = every pair on the register-strip kernels (PWA_SCORES_ROUTE=0: the kernels
+    themselves are under test, whatever the cost model would do with a test-sized list), "routed" = the library's own
+    work-aware choice between the strip and the stripe engine (r03), typically a split on ragged lists."""
+    if request.param == "strips":
+        with switched_context(PWA_SCORES_ROUTE="0") as c:
+            c.route = "strips"
+            yield c
+    else:
+        c = pkg.Context(0)
+        c.route = "routed"
+        yield c
+        c.close()
+
+
 @pytest.fixture(scope="session")
 def ctx(pkg):
     """A context on GPU 0.  No skip on failure: on the GPU box the HIP path must be the one that runs."""

@@ -176,7 +176,8 @@ def test_device_overlaps_with_dash_symbols_match_reference(ctx):
 
 
 # ------------------------------------------------------------------ scores-only batches
-def test_scores_c3_small_fixture(ctx):
+def test_scores_c3_small_fixture(sctx):
+    ctx = sctx
     c3 = load_golden("c3_small")
     pats = [O.gen(1, 0, i, c3["pattern_len"]) for i in range(c3["n_patterns"])]
     txts = [O.gen(1, 1, i, c3["text_len"]) for i in range(c3["n_texts"])]
@@ -194,7 +195,8 @@ def test_scores_c3_small_fixture(ctx):
         assert [list(x) for x in zip(s, ei, ej)] == tab
 
 
-def test_scores_c4_small_fixture(ctx):
+def test_scores_c4_small_fixture(sctx):
+    ctx = sctx
     c4 = load_golden("c4_small")
     seqs = [O.gen(1, 2, i, c4["len"]) for i in range(c4["n_seq"])]
     pa, pb = [], []
@@ -211,7 +213,8 @@ def test_scores_c4_small_fixture(ctx):
 
 
 @pytest.mark.parametrize("alphabet", [b"ACGT", b"ACGTN", bytes(range(65, 91)), bytes(range(1, 256))])
-def test_scores_random_batches_match_oracle(ctx, alphabet):
+def test_scores_random_batches_match_oracle(sctx, alphabet):
+    ctx = sctx
     rng = random.Random(len(alphabet))
     lens = [0, 1, 2, 3, 4, 5, 63, 64, 65, 127, 128, 129, 151, 152, 153, 200, 300, 520]
     seqs = []
@@ -243,7 +246,8 @@ def test_scores_end_cells_match_oracle(ctx):
                 assert (s[k], ei[k], ej[k]) == tuple(w), (mode, sc, k)
 
 
-def test_scores_many_strips_and_long_texts(ctx):
+def test_scores_many_strips_and_long_texts(sctx):
+    ctx = sctx
     """patterns spanning several register strips, texts with every length residue mod 4."""
     pats = [O.gen(3, 0, i, n) for i, n in enumerate([1000, 999, 700, 513, 512, 511, 129, 1])]
     txts = [O.gen(3, 1, i, m) for i, m in enumerate([2000, 2001, 2002, 2003, 5])]
@@ -275,7 +279,7 @@ def test_two_strip_tasks_through_the_lds_paired_kernel(ctx):
                 if (i >= 90) == short_text and rng.random() < 0.9:
                     pa.append(i)
                     pb.append(len(pats) + j)
-        with switched_context(PWA_PAIRED="1") as c:   # opt-in form (a switch of the context)
+        with switched_context(PWA_PAIRED="1", PWA_SCORES_ROUTE="0") as c:   # opt-in form (a switch of the context)
             b = c.batch("sw", seqs, pa, pb, *scoring)
             assert "pair_kernel" in b.info()["kernel"], b.info()
             for _ in range(2):
@@ -289,7 +293,7 @@ def test_two_strip_tasks_through_the_lds_paired_kernel(ctx):
 
 @pytest.mark.parametrize("alphabet,expect_lanes", [(b"ACGT", True), (b"ACGTN", True), (b"ACGTNXY", False),
                                                    (bytes(range(65, 91)), True), (bytes(range(0, 256)), False)])
-def test_index_paired_lists_use_per_lane_texts(ctx, alphabet, expect_lanes):
+def test_index_paired_lists_use_per_lane_texts(sctx, alphabet, expect_lanes):
     """the reference's own shape -- pattern i against reference i (hw2.cpp:328-338), every pair its own text: local
     scores come from the LANES kernels (each lane streams its own text; columns past a lane's text and rows past its
     pattern are padded with two different never-matching symbols).  Ragged lengths in both directions, texts of every
@@ -312,12 +316,13 @@ def test_index_paired_lists_use_per_lane_texts(ctx, alphabet, expect_lanes):
     pa = list(range(n_pairs))
     pb = [n_pairs + k for k in range(n_pairs)]
     for sc in [(1, -1, -1), (2, -3, -5), (5, -4, -4), (3, 0, 0)]:
-        b = ctx.batch("sw", seqs, pa, pb, *sc)
+        b = sctx.batch("sw", seqs, pa, pb, *sc)
         kern = b.info()["kernel"]
         b.run()
         got = b.fetch()
         b.close()
-        assert ("LANES" in kern) == expect_lanes, (kern, sc)
+        if sctx.route == "strips":
+            assert ("LANES" in kern) == expect_lanes, (kern, sc)
         want = [O.score("sw", seqs[a], seqs[c], *sc)[0] for a, c in zip(pa, pb)]
         bad = [k for k in range(n_pairs) if got[k] != want[k]]
         assert not bad, (kern, sc, bad[:5], [(len(pats[k]), len(txts[k]), got[k], want[k]) for k in bad[:5]])
@@ -325,7 +330,7 @@ def test_index_paired_lists_use_per_lane_texts(ctx, alphabet, expect_lanes):
 
 @pytest.mark.parametrize("alphabet,pattern_extra,expect_lanes", [(b"ACGT", b"", True), (b"AC", b"", True), (b"ACGTN", b"", False),
                                                                  (b"ACGT", b"N", False)])
-def test_index_paired_global_scores_use_right_aligned_lanes(ctx, alphabet, pattern_extra, expect_lanes):
+def test_index_paired_global_scores_use_right_aligned_lanes(sctx, alphabet, pattern_extra, expect_lanes):
     """global alignment scores of index-paired lists: LANES kernels with right-aligned texts whose front padding the
     table scores like a gap column (alphabets of <= 4 symbols that contain every pattern symbol); other inputs keep
     the text-grouped form.  Ragged lengths both ways, every length residue mod 4, 1..3 strips, one-symbol and empty
@@ -346,18 +351,20 @@ def test_index_paired_global_scores_use_right_aligned_lanes(ctx, alphabet, patte
     pb = [n_pairs + k for k in range(n_pairs)]
     for sc, shifted in [((1, -1, -1), True), ((2, -3, -5), True), ((5, -4, -4), True), ((1, -1, 0), True), ((3, 0, -2), True),
                         ((100, -90, -70), False)]:
-        b = ctx.batch("nw", seqs, pa, pb, *sc)
+        b = sctx.batch("nw", seqs, pa, pb, *sc)
         kern = b.info()["kernel"]
         b.run()
         got = b.fetch()
         b.close()
-        assert ("LANES" in kern) == (expect_lanes and shifted), (kern, sc)
+        if sctx.route == "strips":
+            assert ("LANES" in kern) == (expect_lanes and shifted), (kern, sc)
         want = [O.score("nw", seqs[a], seqs[c], *sc)[0] for a, c in zip(pa, pb)]
         bad = [k for k in range(n_pairs) if got[k] != want[k]]
         assert not bad, (kern, sc, bad[:5], [(len(pats[k]), len(txts[k]), got[k], want[k]) for k in bad[:5]])
 
 
-def test_index_paired_short_patterns_single_strip_lanes(ctx):
+def test_index_paired_short_patterns_single_strip_lanes(sctx):
+    ctx = sctx
     """per-lane texts with every pattern inside one register strip (the hand-off free LANES instantiation)"""
     rng = random.Random(31)
     n_pairs = 500
@@ -368,14 +375,15 @@ def test_index_paired_short_patterns_single_strip_lanes(ctx):
     pb = [n_pairs + k for k in range(n_pairs)]
     for sc in [(1, -1, -1), (2, -3, -5)]:
         b = ctx.batch("sw", seqs, pa, pb, *sc)
-        assert "LANES" in b.info()["kernel"], b.info()
+        assert "LANES" in b.info()["kernel"] or sctx.route != "strips", b.info()
         b.run()
         got = b.fetch()
         b.close()
         assert got == [O.score("sw", seqs[a], seqs[c], *sc)[0] for a, c in zip(pa, pb)], sc
 
 
-def test_batch_object_reuse(ctx, pkg):
+def test_batch_object_reuse(sctx, pkg):
+    ctx = sctx
     seqs = [O.gen(9, 0, i, 150) for i in range(130)] + [O.gen(9, 1, 0, 777)]
     pa = list(range(130))
     pb = [130] * 130
@@ -388,6 +396,55 @@ def test_batch_object_reuse(ctx, pkg):
     assert b.fetch() == first
     assert b.last_ms() > 0
     assert first == [O.score("sw", s, seqs[130], 1, -1, -1)[0] for s in seqs[:130]]
+    b.close()
+
+
+def test_scores_pass_is_routed_by_work(ctx):
+    """r03: the scores pass over hw2.cpp's pair loop (328-338) picks its engine from the WORK, pair by pair.  A list of few
+    long pairs leaves the lane-per-pair strip kernels (one 10k x 10k pair was one lane of one wave: 779 ms against 1.7 ms),
+    a list of many short pairs plus a few long ones is split, and results land in caller order whatever the split --
+    scores against the oracle, both modes, and the same lists forced onto either engine."""
+    rng = random.Random(303)
+    longs = [(O.gen(30, 0, i, 3000 + 500 * i), O.gen(30, 1, i, 3500 - 300 * i)) for i in range(3)]
+    shorts = [(O.gen(31, 0, i, rng.randint(20, 150)), O.gen(31, 1, i, rng.randint(100, 400))) for i in range(30000)]
+
+    def lists():
+        yield "3 long only", longs, True, False
+        mixed = shorts[:400] + [longs[0]] + shorts[400:] + [longs[2]]
+        yield "30000 short + 2 long", mixed, True, True   # enough short pairs to fill the strips' waves: they stay, the long ones move
+        yield "1 long", longs[:1], True, False
+        yield "1000 short", shorts[:1000], None, None      # (16 wave tasks: cheaper spread over stripes; whatever the model says, exact)
+
+    for name, pairs, want_stripes, want_strips in lists():
+        seqs = [p for p, _ in pairs] + [t for _, t in pairs]
+        pa = list(range(len(pairs)))
+        pb = [len(pairs) + k for k in range(len(pairs))]
+        for mode in ("nw", "sw"):
+            want = [O.score(mode, p, t, 1, -1, -1)[0] for p, t in pairs]
+            b = ctx.batch(mode, seqs, pa, pb, 1, -1, -1)
+            kern = b.info()["kernel"]
+            b.run()
+            got = b.fetch()
+            b.close()
+            assert got == want, (name, mode, kern)
+            if want_stripes is not None:
+                assert ("pair_fill_kernel" in kern) == want_stripes and ("batch_scores_kernel" in kern) == want_strips, (name, mode, kern)
+            for route in ("0", "1"):
+                with switched_context(PWA_SCORES_ROUTE=route) as c:
+                    assert c.scores(mode, seqs, pa, pb, 1, -1, -1) == want, (name, mode, route)
+    # the device score vector of a split batch is complete in caller-owned memory too (what bench.py hands to the all-gather)
+    import torch
+    pairs = shorts[:20000] + [longs[1]]
+    seqs = [p for p, _ in pairs] + [t for _, t in pairs] + [b""]
+    pa = list(range(len(pairs))) + [0]
+    pb = [len(pairs) + k for k in range(len(pairs))] + [2 * len(pairs)]
+    b = ctx.batch("nw", seqs, pa, pb, 2, -3, -5)
+    assert "pair_fill_kernel" in b.info()["kernel"] and "batch_scores_kernel" in b.info()["kernel"], b.info()
+    t = torch.full((len(pa),), -777, dtype=torch.int32, device="cuda")
+    b.set_d_scores(t.data_ptr())
+    b.run()
+    b.last_ms()
+    assert t.cpu().tolist() == [O.score("nw", seqs[a], seqs[c], 2, -3, -5)[0] for a, c in zip(pa, pb)]
     b.close()
 
 
@@ -563,7 +620,8 @@ def test_batches_driven_from_other_threads(pkg):
     c2.close()
 
 
-def test_device_score_vector_in_caller_memory(ctx):
+def test_device_score_vector_in_caller_memory(sctx):
+    ctx = sctx
     """pwa_batch_set_d_scores: kernels write into a torch tensor (what bench.py hands to the RCCL all-gather);
     both engines, including pairs with an empty side."""
     import torch
@@ -599,7 +657,8 @@ def test_whole_matrices_match_reference_matrices(ctx):
                 assert np.array_equal(tb, wtb), (mode, n, m, sc)
 
 
-def test_scores_degenerate_shapes(ctx):
+def test_scores_degenerate_shapes(sctx):
+    ctx = sctx
     """empty batch, texts shorter than one 4-column block, very long pattern against tiny texts,
     duplicate pairs, a pattern aligned with itself."""
     assert ctx.scores("sw", [b"ACGT"], [], [], 1, -1, -1) == []
@@ -652,6 +711,7 @@ def test_full_size_c3_batch_properties(ctx):
     pa = np.repeat(np.arange(4096, dtype=np.uint32), 256)
     pb = np.tile(np.arange(256, dtype=np.uint32) + np.uint32(4096), 4096)
     b = ctx.batch("sw", seqs, pa, pb, 1, -1, -1)
+    assert b.info()["kernel"] == "batch_scores_kernel<R=76,BM_SWS,SC_PERM>", b.info()   # the work-aware routing keeps a full list on the strips
     b.run()
     s = b.fetch(numpy_out=True)
     b.close()
@@ -712,6 +772,7 @@ def test_full_size_c4_all_pairs_properties(ctx):
     pa, pb = ii.astype(np.uint32), jj.astype(np.uint32)
     assert len(pa) == 523776
     b = ctx.batch("nw", seqs, pa, pb, 1, -1, -1)
+    assert b.info()["kernel"].startswith("batch_scores_kernel<R=128,BM_NWG,SC_PERM>"), b.info()   # routed by work: the strips keep (nearly) all of it
     b.run()
     s = b.fetch(numpy_out=True)
     b.close()
