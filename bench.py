@@ -267,47 +267,12 @@ def self_launch(args):
     sys.exit(rc)
 
 
-class _RehearsalBatch:
-    """--rehearse-cpu ONLY: stands in for the HIP batch object so that the launcher, the sharding and the collective of
-    this script can be driven on a machine without a GPU (tests/test_bench_launcher.py: gloo, world 2).  Compute = the
-    CPU oracle.  The line it produces is marked invalid; the product path never comes here."""
-
-    def __init__(self, mode, seqs, pa, pb, scoring):
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O
-        self._O, self._mode, self._seqs, self._pa, self._pb, self._sc = O, mode, seqs, pa, pb, scoring
-        self.n_pairs = len(pa)
-        self._out = None
-        self._times = []
-
-    def info(self):
-        cells = sum(len(self._seqs[a]) * len(self._seqs[b]) for a, b in zip(self._pa.tolist(), self._pb.tolist()))
-        return dict(cells=cells, padded_cells=cells, n_tasks=self.n_pairs, kernel="cpu-oracle-rehearsal")
-
-    def set_out(self, tensor):
-        self._out = tensor
-
-    def run(self, stream=None):
-        t0 = time.perf_counter()
-        sc = [_cpu_one(self._mode, self._O, "port", self._seqs[a], self._seqs[b], self._sc)
-              for a, b in zip(self._pa.tolist(), self._pb.tolist())]
-        self._scores = np.asarray(sc, dtype=np.int32)
-        if self._out is not None:
-            import torch
-            self._out.copy_(torch.from_numpy(self._scores))
-        self._times.append((time.perf_counter() - t0) * 1e3)
-
-    def fetch_into(self, arr):
-        arr[:] = self._scores
-
-    def last_ms(self):
-        return self._times[-1]
-
-    def run_times(self, cap=64):
-        return self._times[-cap:]
-
-    def close(self):
-        pass
+def rehearsal():
+    """--rehearse-cpu ONLY: the CPU stand-ins of tests/rehearsal_batch.py (test infrastructure: gloo + the oracle as compute, so that the
+    launcher, the sharding and the collective of this script can be driven without a GPU; the line is marked invalid)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rehearsal_batch
+    return rehearsal_batch
 
 
 # ----------------------------------------------------------------------------- main
@@ -379,7 +344,7 @@ def main():
         ctx = pkg.Context(local_rank)
 
     if args.workload in ("g", "gb"):
-        return bench_global_batch(args, pkg, ctx)
+        return bench_global_batch(args, pkg, ctx, rank, world, dist if use_dist else None, torch, dist_info, cpu)
     if args.workload in ("c2", "c2b", "c5"):
         return bench_single_pair(args, pkg, ctx, rank, world, dist if use_dist else None, torch)
 
@@ -410,7 +375,7 @@ def main():
     def make_batch(packed=None):   # packed: the blob + offsets form a compiled host already holds (pack_sequences)
         src = packed if packed is not None else seqs
         if cpu:
-            return _RehearsalBatch(mode, seqs, pa, pb, scoring)
+            return rehearsal().RehearsalBatch(mode, seqs, pa, pb, scoring)
         if mode == "affine":
             return ctx.batch_affine(src, pa, pb, *scoring)
         if mode == "nwdist":
@@ -608,33 +573,71 @@ def main():
         sys.exit(3)   # a full-size line that failed its own checks must not look like a result
 
 
-def bench_global_batch(args, pkg, ctx):
+def bench_global_batch(args, pkg, ctx, rank=0, world=1, dist=None, torch=None, dist_info=None, cpu=False):
     """The `-g` shape: FULL alignments (fill + traceback band + walk) of many index-paired short patterns x long
-    texts (hw2.cpp:328-338 with global = true), 1 GPU."""
-    n_pairs = 256 if args.small else 4096
+    texts (hw2.cpp:328-338 with global = true).  N > 1: the pair list of 4096 N pairs is dealt in contiguous blocks of
+    4096 (weak scaling: every rank its own patterns), one all-gather of the per-pair scores and op counts per step."""
+    n_pairs = (8 if cpu else 256) if args.small else 4096
+    tlen, n_txt = (200, 4) if cpu else (10000, 256)
     bands = args.workload == "gb"   # gb: Smith-Waterman with the int32 score band ALSO written (5 B/cell, SURVEY.md 8d)
     mode = "sw" if bands else "nw"
+    if cpu:
+        ctx = rehearsal().RehearsalContext()
     ctx.set_score_band(bands)
-    plen = args.plen
-    pats = [gen(1, 0, p, plen) for p in range(n_pairs)]
-    txts = [gen(1, 1, t, 10000) for t in range(256)]
+    plen = 40 if cpu else args.plen
+    pats = [gen(1, 0, rank * n_pairs + p, plen) for p in range(n_pairs)]   # rank r: block r of the global pair list
+    txts = [gen(1, 1, t, tlen) for t in range(n_txt)]
     seqs = pats + txts
     # host buffers as a compiled host holds them (hw2_amd: the FASTA reader's blob + offsets, the pair list, one op buffer that is
     # reused): built once, outside the timed region -- a step is pwa_align_batch on them, results back in host memory
-    packed = pkg.pack_sequences(seqs)
+    packed = (None, None, seqs) if cpu else pkg.pack_sequences(seqs)
     pa = np.arange(n_pairs, dtype=np.uint32)
-    pb = (n_pairs + (np.arange(n_pairs) % 256)).astype(np.uint32)
+    pb = (n_pairs + (np.arange(n_pairs) % n_txt)).astype(np.uint32)
     out = None
-    for _ in range(args.warmup):
+    state = {"gathered": None}
+    dev = "cpu" if cpu else "cuda"
+
+    def step(out):
         out = ctx.align_batch_arrays(mode, packed, pa, pb, 1, -1, -1, out)
+        if dist is not None:   # the path's only exchange: per-pair scores + op counts of every rank's block (hw2.cpp:342-357 selects over all pairs)
+            mine = torch.from_numpy(np.stack([out["scores"][:n_pairs].astype(np.int32), out["n_ops"][:n_pairs].astype(np.int32)])).to(dev)
+            if state["gathered"] is None:
+                state["gathered"] = torch.empty((world,) + tuple(mine.shape), dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(state["gathered"], mine)
+        return out
+
+    for _ in range(args.warmup):
+        out = step(out)
+    if dist is not None:
+        dist.barrier()
+        if not cpu:
+            torch.cuda.synchronize()
     t0 = time.perf_counter()
     fill, tb = [], []
     for _ in range(args.steps):
-        out = ctx.align_batch_arrays(mode, packed, pa, pb, 1, -1, -1, out)
+        out = step(out)
         st = ctx.align_stats()
         fill.append(st["fill_ms"])
         tb.append(st["traceback_ms"])
+    if dist is not None:
+        dist.barrier()
+        if not cpu:
+            torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gathered_same, gathered_sum = None, None
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        g = state["gathered"].to(torch.int64).flatten()
+        dig = torch.stack([g.sum(), (g * (torch.arange(g.numel(), device=g.device) % 1009 + 1)).sum()])
+        digs = [torch.empty_like(dig) for _ in range(world)]
+        dist.all_gather(digs, dig)
+        gathered_same = all(bool((d == digs[0]).all().item()) for d in digs)
+        gathered_sum = int(state["gathered"][:, 0, :].to(torch.int64).sum().item())
+        if rank != 0:
+            dist.destroy_process_group()
+            return
     res = [dict(score=int(out["scores"][k]), ops=out["ops"][int(out["ops_off"][k]):int(out["ops_off"][k]) + int(out["n_ops"][k])])
            for k in range(n_pairs)]
     # a seeded sample of the batch against the CPU oracle, op for op (after the timed region)
@@ -645,31 +648,50 @@ def bench_global_batch(args, pkg, ctx):
     for k in rs.choice(n_pairs, size=min(n_pairs, 24), replace=False):
         want = O.align(mode, seqs[int(pa[k])], seqs[int(pb[k])], 1, -1, -1, compact=True)
         verified = verified and want["score"] == res[k]["score"] and want["ops"] == res[k]["ops"].tobytes()
-    cells = float(n_pairs) * plen * 10000
+    cells = float(n_pairs) * plen * tlen
     st = ctx.align_stats()
     k_ms = float(np.mean(fill))
+    # the algorithmic bytes of a fill are 1 B (traceback code) -- or 5 B with the int32 score band -- per CELL of the
+    # matrices, plus the inputs once; what the kernels actually write (band padding included) is reported next to it, never as `achieved`
+    alg_bytes = cells * (5 if bands else 1) + sum(len(x) for x in seqs)
+    written = float(st["band_bytes"])
+    rl = next((r for r in (4, 6, 8, 10, 12, 16) if plen <= 16 * r), None)
+    kern = ("mini_fill_kernel<RL=%d,%s%s>" % (rl, "SW,SBAND" if bands else "NW,GAP0", "") if rl else
+            "pair_fill_kernel<RL=%d,W=4,%s,TB%s,PERM%s>" % (2 if plen <= 32768 else 4, mode.upper(), ",SBAND" if bands else "", "" if bands else ",GAP0"))
     line = {
         "metric": "GCUPS (billion DP cells/s) %s full alignments of a pair batch (-g shape); bit-exact vs hw2.cpp" % mode.upper(),
-        "value": cells * args.steps / elapsed / 1e9, "unit": "GCUPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "value": cells * world * args.steps / elapsed / 1e9, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32", "data": "synthetic",
-        "config": {"workload": ("gb: %d pairs %d x 10000, SW fill writing int32 score band + traceback band (5 B/cell) + walk"
-                                if bands else "g: %d pairs %d x 10000, NW fill + traceback band + walk, host buffers in and ops out") % (n_pairs, plen),
+        "config": {"workload": ("gb: %d pairs %d x %d per GPU, SW fill writing int32 score band + traceback band (5 B/cell) + walk"
+                                if bands else "g: %d pairs %d x %d per GPU, NW fill + traceback band + walk, host buffers in and ops out") % (n_pairs, plen, tlen),
                    "scoring": [1, -1, -1]},
-        "roofline": {"bound": "hbm", "kernel": "pair_fill_kernel<RL=4,W=1,%s,TB%s,PERM%s>" % (mode.upper(), ",SBAND" if bands else "", "" if bands else ",GAP0"),
-                     "launches_per_step": "the batch runs as chunks of <= 6 GiB (10 GiB with the score band) of band: achieved / kernel_ms are sums over the step's fill launches", "achieved": st["band_bytes"] / (k_ms * 1e-3) / 1e9,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": st["band_bytes"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": st["band_bytes"], "kernel_ms": k_ms,
-                     "traceback_ms": float(np.mean(tb)), "kernel_gcups": cells / (k_ms * 1e-3) / 1e9},
+        "step_includes": "H2D of the block's sequences, fill, walk, D2H of scores and op lists" + (" + all-gather of per-pair scores and op counts" if dist is not None else ""),
+        "roofline": {"bound": "hbm", "kernel": kern,
+                     "launches_per_step": "the batch runs as ranges of <= 6 GiB (10 GiB with the score band) of band: achieved / kernel_ms are sums over the step's fill launches",
+                     "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_step": alg_bytes,
+                     "algorithmic_bytes_rule": "SURVEY.md 8(d): n * m * %d B per pair (the reference's own %s) + the inputs once" % (5 if bands else 1, "int + char matrices, hw2.cpp:193-194" if bands else "char matrix, hw2.cpp:120"),
+                     "written_bytes_per_step": written, "written_over_algorithmic": written / alg_bytes if alg_bytes else None,
+                     "written_bytes_note": "band bytes the fill kernels store, padding rows / steps of the band geometry included (from the library's own layout; PMC WRITE_SIZE: profiles/traffic_%s.json)" % args.workload,
+                     "traffic": None, "kernel_ms": k_ms, "traceback_ms": float(np.mean(tb)), "kernel_gcups": cells / (k_ms * 1e-3) / 1e9},
         "result": {"score_sum": int(sum(r["score"] for r in res)), "ops_total": int(sum(len(r["ops"]) for r in res))},
         "verified_vs_cpu": {"pairs": int(min(n_pairs, 24)), "what": "score and op list against the CPU oracle", "bit_exact": bool(verified)},
     }
+    if dist_info is not None:
+        line["dist"] = dict(dist_info, gathered_identical_on_all_ranks=gathered_same, gathered_score_sum=gathered_sum)
+        if not gathered_same:
+            line["invalid"] = "the gathered vectors differ between ranks"
     attach_traffic(line["roofline"], args.workload)
     if not verified:
         line["invalid"] = "GPU alignments differ from the CPU oracle"
     if args.small:
         line["invalid"] = "reduced sizes (--small): functional check only"
+    if cpu:
+        line["invalid"] = "CPU rehearsal of the launcher / sharding / collective (gloo + oracle): not a measurement"
     print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def bench_single_pair(args, pkg, ctx, rank, world, dist, torch):
@@ -706,7 +728,8 @@ def bench_single_pair(args, pkg, ctx, rank, world, dist, torch):
     st = ctx.align_stats()
     cells = float(n) * m
     k_ms = float(np.mean(fill))
-    band = st["band_bytes"]
+    written = float(st["band_bytes"])
+    band = cells * (5 if args.workload == "c2b" else 1) + n + m   # n * m * (1 | 5) B + the inputs; `written` counts the band's padding too
     line = {
         "metric": "GCUPS (billion DP cells/s) single pair with traceback; bit-exact vs hw2.cpp",
         "value": cells * world * args.steps / elapsed / 1e9, "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
@@ -717,7 +740,8 @@ def bench_single_pair(args, pkg, ctx, rank, world, dist, torch):
         "roofline": {"bound": "hbm", "kernel": ("pair_fill_kernel<RL=2,W=4,SW,TB,PERM>" if mode == "sw" else "pair_fill_kernel<RL=4,W=4,NW,TB,PERM,GAP0>"),
                      "achieved": band / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": band / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": band, "kernel_ms": k_ms, "traceback_ms": float(np.mean(tb)),
+                     "algorithmic_bytes_per_launch": band, "written_bytes_per_launch": written, "written_over_algorithmic": written / band,
+                     "kernel_ms": k_ms, "traceback_ms": float(np.mean(tb)),
                      "kernel_gcups": cells / (k_ms * 1e-3) / 1e9},
         "result": {"score": r["score"], "n_ops": len(r["ops"])},
     }

@@ -113,7 +113,8 @@ def _b(x):
 
 def pack_sequences(seqs):
     """list of bytes -> (concatenated bytes, uint64 offsets[n+1], the list); an already packed triple passes through"""
-    if isinstance(seqs, tuple) and len(seqs) == 3 and isinstance(seqs[0], (bytes, bytearray)):
+    if (isinstance(seqs, tuple) and len(seqs) == 3 and isinstance(seqs[0], (bytes, bytearray)) and isinstance(seqs[1], C.Array)
+            and getattr(seqs[1], "_type_", None) is C.c_uint64 and isinstance(seqs[2], list)):   # (a tuple of three byte strings is a list of sequences)
         return seqs
     seqs = [_b(s) for s in seqs]
     off = (C.c_uint64 * (len(seqs) + 1))()
@@ -310,7 +311,9 @@ class Context:
         self._check(rc, "pwa_align_matrices")
         return dp, tb
 
-    def align_batch(self, mode, seqs, pair_a, pair_b, match, mismatch, gap):
+    def align_batch(self, mode, seqs, pair_a, pair_b, match, mismatch, gap, region_pad=0):
+        """region_pad > 0: every pair's op region starts at a multiple of region_pad (a caller with aligned regions; the library then
+        returns the op lists through its staging copy instead of one tiled copy)."""
         blob, off, seqs = pack_sequences(seqs)
         n = len(pair_a)
         pa = (C.c_uint32 * max(n, 1))(*pair_a)
@@ -318,6 +321,8 @@ class Context:
         ooff = (C.c_uint64 * max(n, 1))()
         tot = 0
         for k in range(n):
+            if region_pad:
+                tot = (tot + region_pad - 1) // region_pad * region_pad + (region_pad if k % 3 == 1 else 0)
             ooff[k] = tot
             tot += len(seqs[pair_a[k]]) + len(seqs[pair_b[k]])
         ops = C.create_string_buffer(tot + 1)

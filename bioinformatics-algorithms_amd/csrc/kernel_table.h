@@ -5,6 +5,7 @@
 #include "batch_affine.hip.h"
 #include "batch_nwdist.hip.h"
 #include "pair_fill.hip.h"
+#include "mini_fill.hip.h"
 
 namespace pwa {
 
@@ -32,5 +33,10 @@ const BatchKernelEntry* find_batch_kernel(int R, int mode, int score);
 // gap0: global fill in gap-shifted coordinates (the host passes gap 0 and scores s - 2 gap): perm && keyed && !sband only
 pair_kernel_t pair_fill_kernel_for(int rl, int w, bool local, bool tb, bool sband, bool perm, bool keyed = true, bool gap0 = false);
 pair_kernel_t pair_traceback_kernel_for(int rl, bool local, int walk);   // walk: WALK_NONE / WALK_OPS / WALK_OVERLAP
+// mini_kernels*.hip -- the mini-stripe engine (16 lanes per pair, 4 pairs per wave; keyed cells, table scoring): fills for
+// rl in kMiniRL; gap0 only global without score band; the walks over its band geometry (BandGeo<16, rl>)
+constexpr int kMiniRL[] = {4, 6, 8, 10, 12, 16};
+pair_kernel_t mini_fill_kernel_for(int rl, bool local, bool sband, bool gap0);
+pair_kernel_t mini_traceback_kernel_for(int rl, bool local, int walk);
 
 }  // namespace pwa

@@ -1,0 +1,250 @@
+// mini_fill.hip.h -- DP fill with the traceback band in HBM for MANY pairs with SHORT patterns (gfx950 / MI355X).
+//
+// Replaces, like pair_fill.hip.h, hw2.cpp:119-156 (NW) / 193-231 (SW) -- for the shape of hw2's own `-g` runs: a few
+// thousand (pattern i, reference i) pairs of ~150-row patterns (hw2.cpp:328-338), every one of which needs its traceback
+// (hw2.cpp:344).
+//
+// Why a third mapping.  The stripe engine gives a pair one wave: 64 lanes x RL rows, i.e. a 150-row pattern runs as a
+// 256-row stripe (41 % of the lanes' work and of the band bytes are padding) behind a helper wave that only stages text.
+// A lane-per-pair kernel (the strip engine's mapping) would need 5 VALU per cell instead of ~14 per useful cell -- but
+// 4096 pairs are 64 waves on a chip of 1024 SIMDs, each running 150 x 10 000 cells on its own: ~20 ms.  The middle:
+//   * a pair = ONE DPP row of 16 lanes, lane k owns RL consecutive rows (RL = 4 .. 16: patterns of up to 256 rows, 160 for
+//     RL = 10), a wave = 4 independent pairs: 4096 pairs are 1024 waves -- one per SIMD -- and a step's fixed costs (DPP
+//     moves, text, store) are spread over 4 x RL rows instead of 4;
+//   * the anti-diagonal front, the keyed cells (H * 4 + priority, one v_max3 per cell), table scoring on coded symbols,
+//     the gap-shifted global form and the guarded chunks are pair_fill.hip.h's; `row_shr:1` moves a value from lane k-1
+//     to lane k inside each 16-lane row, `row_shl:q` with bank mask 1 puts the staged text symbol of step q into lane 0
+//     of every row at once -- the same two DPP moves the stripe engine uses, now serving four pairs;
+//   * nothing comes from another wave: the row above a pair is the matrix's row 0 (a constant per step), the text is
+//     prefetched by the lanes themselves (one byte per lane and 16-step chunk, a chunk ahead) -- no helper wave, no LDS,
+//     no flags, no hand-off rows;
+//   * band: per pair [step t][16 lanes][RL code bytes] in two planes per step (BandGeo<16, RL>), written with one aligned
+//     4 / 8 / 16-byte store (+ one 2 / 4-byte store) per lane and step: every 16-lane row writes 16 RL contiguous bytes.
+//     160 instead of 256 band bytes per column for a 150-row pattern.  The optional int32 score band is [t][16][RL].
+// Tasks (4 pairs) come off an atomic queue; the host sorts pairs by text length so that a task's pairs run about the same
+// number of steps, pads the list to whole tasks with empty patterns, and sizes every band for its task's longest text.
+#pragma once
+#include "pair_fill.hip.h"
+
+namespace pwa {
+
+// band steps of a mini-stripe pair whose task's longest text has m columns: m + 15 anti-diagonal steps in whole 16-step chunks
+__host__ __device__ inline size_t mini_band_steps(size_t m) { return (m + 15 + 15) & ~(size_t)15; }
+
+typedef uint32_t mu32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t mu32x4 __attribute__((ext_vector_type(4)));
+
+// lanes 1..15 of every row <- lane k-1 of v; lane 0 of every row keeps dst
+__device__ __forceinline__ int mini_row_shr1(int dst, int v) { return __builtin_amdgcn_update_dpp(dst, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false); }
+// lane 0 of every row <- lane Q of v in that row (lanes 4, 8, 12 are written too and overwritten by the row_shr:1 that follows)
+template <int Q>
+__device__ __forceinline__ int mini_pick_lane0(int dst, int v) {
+    if constexpr (Q == 0) return __builtin_amdgcn_update_dpp(dst, v, 0xE4 /* quad_perm:[0,1,2,3] */, 0xf, 0x1, false);
+    else return __builtin_amdgcn_update_dpp(dst, v, 0x100 + Q /* row_shl:Q */, 0xf, 0x1, false);
+}
+
+// 16 steps of four pairs.  GUARD: some lane of the wave is outside its matrix at some step of the chunk (the first 15
+// steps, and from the shortest text's last column on): that lane's state is frozen (pair_fill.hip.h, keyed_chunk).
+template <int RL, bool LOCAL, bool SBAND, bool GUARD, bool GAP0>
+__device__ __forceinline__ void mini_chunk(const int t0, const int k, const int m, const uint32_t (&pk)[(RL + 3) / 4], int (&hl)[RL], int& diag0,
+                                           int& bottom, int& tch, const int tcv, const int top0, const int top_inc, int (&bs)[RL], int (&bj)[RL],
+                                           const uint32_t tab_lo, const uint32_t tab_hi, const int cl, g_u8* const tba, g_u8* const tbb,
+                                           g_i32* const sb) {
+    typedef BandGeo<16, RL> Geo;
+    constexpr int NQ = (RL + 3) / 4;
+    constexpr int PU = TbCode<LOCAL>::UP, PL = TbCode<LOCAL>::LEFT;
+    static_assert(!GAP0 || (!LOCAL && !SBAND && PU == 0), "gap-shifted fills: global, no score band");
+    const int cu = p_addw(cl, PU - PL);
+    static_for<0, 16>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const int j = t0 + q - k + 1;
+        const bool act = !GUARD || (unsigned)(j - 1) < (unsigned)m;   // this lane's column is inside its pair's matrix
+        // text symbol (splatted): lane 0 of each row takes the staged symbol of step q, lane k the one lane k-1 had a step ago
+        const int tn = mini_row_shr1(mini_pick_lane0<q>(tch, tcv), tch);
+        uint32_t s4[NQ];
+#pragma unroll
+        for (int x = 0; x < NQ; ++x) s4[x] = __builtin_amdgcn_perm(tab_hi, tab_lo, pk[x] ^ (uint32_t)tn);
+        // the row above: lane k-1's last row of the previous step; lane 0 of each row: the matrix's row 0 (hw2.cpp:131-136 / 193)
+        const int up_in = mini_row_shr1(top0 + q * top_inc, bottom);
+        int dg = diag0, up = up_in;
+        uint32_t codes[NQ];
+        int hsb[RL];
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {
+            const int kd = p_addw(dg, (int)(int8_t)(s4[r / 4] >> (8 * (r % 4))));   // hw2.cpp:142 / 208-211: diag + s, as a key
+            const int kl = hl[r];
+            int kk = max(max(kd, up), kl);                                          // 142-153 / 211-222: value and direction in one max
+            if (LOCAL) kk = max(kk, (int)TB_STOP);
+            const int base = kk & ~3;
+            if (r % 4 == 0) codes[r / 4] = tb_first_code(kk);
+            if (r % 4 == 1) tb_put_code<1>(codes[r / 4], kk);
+            if (r % 4 == 2) tb_put_code<2>(codes[r / 4], kk);
+            if (r % 4 == 3) tb_put_code<3>(codes[r / 4], kk);
+            const int hn = GAP0 ? (base | PL) : p_addw(base, cl);                   // what the next column (left) and the diagonal take
+            if (LOCAL) {
+                if (act && base > bs[r]) {                                          // hw2.cpp:225-229 (bs holds H * 4)
+                    bs[r] = base;
+                    bj[r] = j;
+                }
+            }
+            if (SBAND) hsb[r] = kk >> 2;
+            dg = kl;
+            up = GAP0 ? base : p_addw(base, cu);                                    // what the row below / the lane below takes
+            hl[r] = act ? hn : kl;
+        }
+        const int d0 = p_addw(up_in, PL - PU);                                      // dp[i_first - 1][j] in the left form: next step's diagonal of row 0
+        diag0 = act ? d0 : diag0;
+        bottom = act ? up : bottom;
+        tch = tn;
+        // the step's codes: plane A (PA bytes per lane), plane B (PB bytes per lane)
+        if constexpr (Geo::PA == 4) *(g_u32*)(tba + q * Geo::SR) = codes[0];
+        if constexpr (Geo::PA == 8) *(PWA_GLOBAL mu32x2*)(tba + q * Geo::SR) = mu32x2{codes[0], codes[1]};
+        if constexpr (Geo::PA == 16) *(PWA_GLOBAL mu32x4*)(tba + q * Geo::SR) = mu32x4{codes[0], codes[1], codes[2], codes[3]};
+        if constexpr (Geo::PB == 2) *(PWA_GLOBAL uint16_t*)(tbb + q * Geo::SR) = (uint16_t)codes[Geo::PA / 4];
+        if constexpr (Geo::PB == 4) *(g_u32*)(tbb + q * Geo::SR) = codes[Geo::PA / 4];
+        if (SBAND) {
+#pragma unroll
+            for (int r = 0; r < RL; ++r) sb[q * Geo::SR + r] = hsb[r];
+        }
+    });
+}
+
+template <int RL, bool LOCAL, bool SBAND, bool GAP0>
+__global__ __launch_bounds__(64) void mini_fill_kernel(const PairParams G) {
+    typedef BandGeo<16, RL> Geo;
+    constexpr int NQ = (RL + 3) / 4;
+    constexpr int PU = TbCode<LOCAL>::UP, PL = TbCode<LOCAL>::LEFT;
+    const int lane = threadIdx.x, k = lane & 15, grp = lane >> 4;
+    const int match = G.match, mismatch = G.mismatch, gap = G.gap;
+    // key constants (pair_fill.hip.h): diagonal (s - gap) * 4 + (prio(diag) - prio(left)), left gap * 4 + prio(left); as a byte table
+    const int a_match = (int)(((unsigned)match - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - PL));
+    const int a_mismatch = (int)(((unsigned)mismatch - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - PL));
+    const int cl = (int)((unsigned)gap * 4u + (unsigned)PL);
+    const uint32_t bm = (uint32_t)(uint8_t)(int8_t)a_match, bx = (uint32_t)(uint8_t)(int8_t)a_mismatch;
+    const uint32_t tab_lo = bm | (bx << 8) | (bx << 16) | (bx << 24), tab_hi = bx * 0x01010101u;   // selector 0 -> match, 1..7 -> mismatch
+    for (;;) {
+        uint32_t tid = 0;
+        {
+            int elect = lane;   // opaque electing lane: see batch_scores.hip.h
+            asm volatile("" : "+v"(elect));
+            if (elect == 0) tid = atomicAdd(G.queue, 1u);
+        }
+        tid = __builtin_amdgcn_readfirstlane(tid);
+        if (tid >= G.n_tasks) break;
+        // this row's pair (the host pads the descriptor list to whole tasks with empty patterns on a dump band)
+        const PWA_GLOBAL PairDesc* const P = (const PWA_GLOBAL PairDesc*)(G.pairs + (size_t)tid * 4 + grp);
+        const int n = P->n, m = P->m;
+        g_cu8* const pat = (g_cu8*)P->pat;
+        int mmax = max(m, __shfl_xor(m, 16)), mmin = min(m, __shfl_xor(m, 16));
+        mmax = max(mmax, __shfl_xor(mmax, 32));
+        mmin = min(mmin, __shfl_xor(mmin, 32));
+        mmax = __builtin_amdgcn_readfirstlane(mmax);
+        mmin = __builtin_amdgcn_readfirstlane(mmin);
+        const int n_chunks = (mmax + 15 + 15) / 16;
+        const int i_first = k * RL + 1;   // first row of this lane (1-based)
+        uint32_t pk[NQ];
+        int hl[RL], bs[RL], bj[RL];
+#pragma unroll
+        for (int x = 0; x < NQ; ++x) pk[x] = 0;
+#pragma unroll
+        for (int r = 0; r < 4 * NQ; ++r) {
+            const int i = i_first + r;
+            const uint32_t c = (r < RL && i <= n) ? (uint32_t)pat[i - 1] : 7u;   // code 7 never equals a text symbol
+            pk[r / 4] |= c << (8 * (r % 4));
+        }
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {
+            hl[r] = tb_stored(LOCAL || GAP0 ? 0 : p_mulw(i_first + r, gap), gap, PL);   // dp[i][0], hw2.cpp:125-130 (G: 0)
+            bs[r] = 0;
+            bj[r] = 0;
+        }
+        int diag0 = tb_stored(LOCAL || GAP0 ? 0 : p_mulw(i_first - 1, gap), gap, PL);   // dp[i_first-1][0]
+        // row 0 in the form `bottom` travels in (the up-candidate of the row below): global H = j * gap, G and local 0
+        const int top_inc = (LOCAL || GAP0) ? 0 : (int)((unsigned)gap * 4u);
+        g_u8* const tb = (g_u8*)P->tb;
+        g_i32* const sband = SBAND ? (g_i32*)P->sband : nullptr;
+        const int offa = k * Geo::PA, offb = 16 * Geo::PA + k * Geo::PB;
+        int bottom = 0, tch = 0;
+        // Text staging WITHOUT vector-memory loads: a single VMEM load in the chunk loop makes the wave wait, at every chunk, for all the
+        // band stores issued before it (loads and stores share vmcnt and return in order) -- [gpu, r03] 3.8 ms instead of 1.5 ms for the
+        // 4096 x (150 x 10k) batch.  The four texts are read with SCALAR loads (16 bytes per pair and chunk, a chunk ahead; lgkmcnt) and
+        // each lane picks its byte: dword (lane >> 2) of the 16 loaded, byte (lane & 3) of it.
+        const uint32_t* tg[4];
+        int mg[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const uint64_t tp = (uint64_t)(uintptr_t)P->txt;
+            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)tp, 16 * x), hi = __builtin_amdgcn_readlane((uint32_t)(tp >> 32), 16 * x);
+            tg[x] = (const uint32_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+            mg[x] = __builtin_amdgcn_readlane(m, 16 * x);
+        }
+        auto stage = [&](int t0s, mu32x4 (&w)[4]) {   // bytes t0s .. t0s+15 of every pair's text (clamped: never more than 31 bytes past its end)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int tc = min(t0s, (mg[x] + 15) & ~15);
+                w[x] = *(const __attribute__((address_space(4))) mu32x4*)((uintptr_t)tg[x] + (size_t)tc);
+            }
+        };
+        const uint32_t bsel = (uint32_t)(k & 3) * 0x01010101u;   // v_perm selector: byte (k & 3) of the dword, in all four bytes
+        const int wsel = lane >> 2;
+        mu32x4 wnext[4];
+        stage(0, wnext);
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            const int t0 = ch * 16;
+            uint32_t wv = wnext[0][0];
+#pragma unroll
+            for (int x = 1; x < 16; ++x) wv = (wsel == x) ? wnext[x >> 2][x & 3] : wv;
+            const int tcv = (int)__builtin_amdgcn_perm(wv, wv, bsel);   // lane q of a row: its pair's column t0 + q, splatted (the symbol travels down the lanes that way)
+            stage(t0 + 16, wnext);                                       // a chunk ahead
+            const int top0 = tb_stored(LOCAL || GAP0 ? 0 : p_mulw(t0 + 1, gap), gap, PU);
+            g_u8* const tbs = tb + (size_t)t0 * Geo::SR;
+            g_i32* const sbs = SBAND ? sband + (size_t)t0 * Geo::SR + k * RL : nullptr;
+            const bool interior = t0 >= 15 && t0 + 16 <= mmin;   // every lane of every pair inside its matrix
+            if (interior)
+                mini_chunk<RL, LOCAL, SBAND, false, GAP0>(t0, k, m, pk, hl, diag0, bottom, tch, tcv, top0, top_inc, bs, bj, tab_lo, tab_hi, cl, tbs + offa,
+                                                          tbs + offb, sbs);
+            else
+                mini_chunk<RL, LOCAL, SBAND, true, GAP0>(t0, k, m, pk, hl, diag0, bottom, tch, tcv, top0, top_inc, bs, bj, tab_lo, tab_hi, cl, tbs + offa,
+                                                         tbs + offb, sbs);
+        }
+        PWA_GLOBAL PairResult* const res = (PWA_GLOBAL PairResult*)P->res;
+        if (!LOCAL) {
+            // dp[n][m] (hw2.cpp:186): a lane's state freezes when it leaves the matrix, so the lane that holds row n still has its last
+            // column's stored value H * 4 + gap * 4 + prio(left)
+#pragma unroll
+            for (int r = 0; r < RL; ++r)
+                if (i_first + r == n) res->score = (int)((unsigned)hl[r] - (unsigned)cl) >> 2;
+        } else {
+            // per-lane reduction over row slots, then over the pair's 16 lanes: max score, then smallest i (hw2.cpp:225-229)
+            int s_best = 0, i_best = 0, j_best = 0;
+#pragma unroll
+            for (int r = 0; r < RL; ++r) {
+                const int i = i_first + r;
+                if (i <= n && bs[r] > s_best) {
+                    s_best = bs[r];
+                    i_best = i;
+                    j_best = bj[r];
+                }
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                const int so = __shfl_xor(s_best, off), io = __shfl_xor(i_best, off), jo = __shfl_xor(j_best, off);
+                const bool better = so > s_best || (so == s_best && so > 0 && io < i_best);
+                if (better) {
+                    s_best = so;
+                    i_best = io;
+                    j_best = jo;
+                }
+            }
+            if (k == 0) {
+                g_i32* bp = (g_i32*)(G.best + P->first_stripe);
+                bp[0] = s_best >> 2;
+                bp[1] = i_best;
+                bp[2] = j_best;
+                bp[3] = 0;
+            }
+        }
+    }
+}
+
+}  // namespace pwa

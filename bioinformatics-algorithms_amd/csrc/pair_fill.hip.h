@@ -778,10 +778,33 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
 // window the window before it is already in flight into the second LDS buffer.  The walk state
 // is wave-uniform and lives in SGPRs; the only per-op latency left is one ds_read_u8.
 enum { WALK_NONE = 0, WALK_OPS = 1, WALK_OVERLAP = 2 };   // end cells only / op list / overlap length, no op list
-template <int RL, bool LOCAL, int WALK>
+
+// Where the code of a cell sits inside its band, for the two band geometries:
+//   LN = 64  the stripe engine above: a stripe = 64 lanes x RL rows, one step = 64 RL bytes [lane][RL];
+//   LN = 16  the mini-stripe engine (mini_fill.hip.h): a pair = ONE stripe of 16 lanes x RL rows, one step = 16 RL bytes in two
+//            planes [16 lanes][PA bytes][16 lanes][PB bytes] (PA + PB = RL: what one aligned 4 / 8 / 16-byte store and one
+//            2 / 4-byte store of a lane hold).
+// Cell (i, j): q = i - 1, stripe q / SR, row in stripe ql = q % SR, lane k = ql / RL, band step t = j - 1 + k.
+template <int LN, int RL>
+struct BandGeo {
+    static constexpr int SR = LN * RL;   // rows per stripe = bytes per band step
+    static constexpr int PA = LN == 64 ? RL : (RL >= 16 ? 16 : (RL >= 8 ? 8 : 4)), PB = RL - PA;
+    static_assert(LN == 64 || (LN == 16 && RL >= 4 && RL <= 16 && (PB == 0 || PB == 2 || PB == 4)), "band geometry");
+    __host__ __device__ static inline int stripe(unsigned q) { return (int)(q / (unsigned)SR); }
+    __host__ __device__ static inline int row_in_stripe(unsigned q) { return (int)(q % (unsigned)SR); }
+    __host__ __device__ static inline int lane(int ql) { return (int)((unsigned)ql / (unsigned)RL); }
+    __host__ __device__ static inline int off(int ql) {   // byte of the cell inside its step
+        if (LN == 64) return ql;
+        const int k = (int)((unsigned)ql / (unsigned)RL), r = ql - k * RL;
+        return r < PA ? k * PA + r : LN * PA + k * PB + (r - PA);
+    }
+};
+
+template <int RL, bool LOCAL, int WALK, int LN = 64>
 __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) {
+    typedef BandGeo<LN, RL> Geo;
     constexpr int WIN = 64;                        // steps per LDS window
-    constexpr int STEP_BYTES = 64 * RL;
+    constexpr int STEP_BYTES = LN * RL;
     constexpr int WB = WIN * STEP_BYTES;           // bytes per window (16 KiB for RL = 4)
     __shared__ __attribute__((aligned(16))) uint8_t win[WALK != WALK_NONE ? 2 * WB + 16 : 16];   // + a byte that reads "no code"
     const int lane = threadIdx.x;
@@ -877,8 +900,7 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         // hops 5.2 ms (16 k trips); five views 4.8 ms (8.2 k); both windows readable 7.5 k trips; seven views 4.6 ms (5.8 k);
         // nine views 4.7 ms (4.8 k trips, but 100 SGPRs and a longer set-up).  Timing-only builds: hops without their store
         // and exec writes -0.4 ms, no waits for the prefetched window -0.0 ms: what is left is the instruction count.
-        constexpr int SH = RL == 4 ? 8 : RL == 2 ? 7 : 6, RSH = RL == 4 ? 2 : RL == 2 ? 1 : 0, SR = 64 * RL;
-        static_assert(SR == (1 << SH), "stripe rows");
+        constexpr int SR = Geo::SR;   // (for the stripe engine's power-of-two geometries every / and % below is a shift or a mask)
         constexpr uint32_t OPTAB = LOCAL ? ((uint32_t)'I' | (uint32_t)'D' << 8 | (uint32_t)'M' << 16)    // local: l 0, u 1, d 2
                                          : ((uint32_t)'D' | (uint32_t)'I' << 8 | (uint32_t)'M' << 16);   // global: u 0, l 1, d 2
         constexpr int NOCODE = 2 * WB;
@@ -899,7 +921,7 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         while (i > 0 && j > 0) {
             {   // make sure the window holding (i, j) is staged (wave-uniform)
                 const unsigned q0 = (unsigned)(i - 1);
-                const int s0 = (int)(q0 >> SH), k0 = (int)((q0 & (SR - 1)) >> RSH);
+                const int s0 = Geo::stripe(q0), k0 = Geo::lane(Geo::row_in_stripe(q0));
                 const int w0 = (int)((unsigned)(j - 1 + k0) / (unsigned)WIN);
                 if (s0 != cur_s || w0 != cur_w) {
                     if (!(s0 == pre_s && w0 == pre_w)) issue(w0 & 1, s0, w0);   // not the window already in flight / landed
@@ -923,15 +945,15 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
             const int tlo = (pre_done ? cur_w - 1 : cur_w) * WIN, jj = j - dl;
             const unsigned span = (unsigned)((cur_w + 1) * WIN - tlo);
             auto staged = [&](int t) { return (unsigned)(t - tlo) < span; };
-            auto lds_at = [&](int t, int ql) { return ((t & (2 * WIN - 1)) << SH) | ql; };
+            auto lds_at = [&](int t, int ql) { return (t & (2 * WIN - 1)) * SR + Geo::off(ql); };
             int code[NV];
             int qlo0 = 0, t0 = 0;
             bool s0v = false;
 #pragma unroll
             for (int r = 0; r <= A; ++r) {                                   // view A - r: the cell r rows above (i-d, j-d)
-                const int q = i - 1 - r - dl, ql = q & (SR - 1);
-                const bool same = (int)((unsigned)q >> SH) == cur_s;         // same stripe (false for rows above the matrix)
-                const int t = jj - 1 + (ql >> RSH);                          // its band step
+                const int q = i - 1 - r - dl, ql = Geo::row_in_stripe((unsigned)q);
+                const bool same = Geo::stripe((unsigned)q) == cur_s;         // same stripe (false for rows above the matrix)
+                const int t = jj - 1 + Geo::lane(ql);                        // its band step
                 code[A - r] = win[same && staged(t) && jj > 0 ? lds_at(t, ql) : NOCODE];
                 if (r == 0) {
                     qlo0 = ql;
@@ -1073,7 +1095,7 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
     while (!OPS && i > 0 && j > 0) {
         {   // make sure the window holding (i, j) is staged (wave-uniform)
             const unsigned q0 = (unsigned)(i - 1);
-            const int s0 = (int)(q0 / (64 * RL)), k0 = (int)((q0 % (64 * RL)) / RL);
+            const int s0 = Geo::stripe(q0), k0 = Geo::lane(Geo::row_in_stripe(q0));
             const int w0 = (j - 1 + k0) / WIN;
             if (s0 != cur_s || w0 != cur_w) {
                 if (s0 == pre_s && w0 == pre_w) cb ^= 1;                 // already in flight into the other buffer
@@ -1093,10 +1115,10 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         int code = 0xff;                                                 // 0xff: not available in this trip
         if (ii > 0 && jj > 0) {
             const unsigned q = (unsigned)(ii - 1);
-            const int s = (int)(q / (64 * RL)), k = (int)((q % (64 * RL)) / RL), r = (int)(q % RL);
-            const int t = jj - 1 + k;
+            const int s = Geo::stripe(q), ql = Geo::row_in_stripe(q);
+            const int t = jj - 1 + Geo::lane(ql);
             const int w = t / WIN;
-            if (s == cur_s && w == cur_w) code = win[cb * WB + ((t - w * WIN) * 64 + k) * RL + r];
+            if (s == cur_s && w == cur_w) code = win[cb * WB + (t - w * WIN) * STEP_BYTES + Geo::off(ql)];
         }
         const unsigned long long dm = __ballot(code == TB_DIAG);
         const int L = (~dm == 0ull) ? 64 : __builtin_ctzll(~dm);        // leading run of diagonal moves

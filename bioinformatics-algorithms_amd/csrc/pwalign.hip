@@ -388,6 +388,7 @@ struct PairLaunch {
     }
     PairParams G{};
     PairGeom geom{4, 4};
+    bool mini = false;   // the mini-stripe engine (mini_fill.hip.h): 16 lanes per pair, geom.rl rows per lane, 4 pairs per wave
     bool perm = false;   // sequences are coded 0..6 (pad 7) and the key constants fit a byte: table-scoring fill kernels
     bool keyed = true;   // traceback fills keep H * 4 + priority (needs |H| < 2^28); false: plain int32 compare-and-select form
     bool gap0 = false;   // global keyed table-scoring fill in gap-shifted coordinates: build() was given gap 0 and scores s - 2 gap
@@ -459,9 +460,60 @@ struct PairLaunch {
         grid = (uint32_t)std::min<uint64_t>(tl.size(), (uint64_t)ctx->num_cu * per_cu);
         return PWA_OK;
     }
+    // mini-stripe engine: pd = the real pairs first (n_real of them), then empty patterns up to a multiple of four; task t = the
+    // pairs 4t .. 4t+3 (the caller orders them so that a task's texts are about equally long)
+    int build_mini(pwa_ctx* ctx, std::vector<PairDesc>& pd, uint32_t n_real, int match, int mismatch, int gap, int rl) {
+        mini = true;
+        geom = PairGeom{rl, 1};
+        if (pd.empty() || pd.size() % 4 || pd.size() >= 0xffffffffull || n_real > pd.size() || n_real + 3 < pd.size())
+            return fail(ctx, PWA_E_INVALID, "internal: mini-stripe task list");
+        for (size_t q = 0; q < pd.size(); ++q) {
+            pd[q].first_task = (uint32_t)(q / 4);
+            pd[q].first_stripe = (uint32_t)q;
+            pd[q].n_stripes = 1;
+            pd[q].row_stride = 0;
+            pd[q].rows = nullptr;
+        }
+        HIPC(ctx, take(ctx, desc, pwa_ctx::POOL_DESC, pd.size() * sizeof(PairDesc), &p_desc));
+        HIPC(ctx, ctx->pin[pwa_ctx::PIN_DESC].reserve(pd.size() * sizeof(PairDesc)));
+        std::memcpy(ctx->pin[pwa_ctx::PIN_DESC].p, pd.data(), pd.size() * sizeof(PairDesc));
+        HIPC(ctx, hipMemcpy(p_desc, ctx->pin[pwa_ctx::PIN_DESC].p, pd.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
+        HIPC(ctx, take(ctx, best, pwa_ctx::POOL_BEST, pd.size() * sizeof(StripeBest), &p_best));
+        HIPC(ctx, take(ctx, queue, pwa_ctx::POOL_QUEUE, 64, &p_queue));
+        progress_bytes = 0;
+        row_bytes = 0;
+        G = PairParams{};
+        G.pairs = static_cast<PairDesc*>(p_desc);
+        G.n_pairs = n_real;
+        G.n_tasks = (uint32_t)(pd.size() / 4);
+        G.queue = static_cast<uint32_t*>(p_queue);
+        G.best = static_cast<StripeBest*>(p_best);
+        G.match = match;
+        G.mismatch = mismatch;
+        G.gap = gap;
+        G.dash = 0x100;
+        G.trace_stripe = -1;
+        n_stripes = pd.size();
+        grid = G.n_tasks;   // (clamped to what the chip holds at launch time, where the kernel is known)
+        return PWA_OK;
+    }
     // enqueue: zero the queue / progress words, fill, then the walk (or only the end-cell pick)
     int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, int walk, hipEvent_t after_fill, bool sband = false) {
         HIPC(ctx, hipMemsetAsync(p_queue, 0, 16, st));
+        if (mini) {
+            const pair_kernel_t fill = mini_fill_kernel_for(geom.rl, local, sband, gap0 && !sband && !local);
+            const pair_kernel_t walk_fn = mini_traceback_kernel_for(geom.rl, local, walk);
+            if (!fill || !walk_fn || !tb || !perm || !keyed) return fail(ctx, PWA_E_INVALID, "internal: no mini-stripe kernel for this form");
+            int per_cu = 0;
+            HIPC(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fill), 64, 0));
+            const uint32_t g = (uint32_t)std::min<uint64_t>(G.n_tasks, (uint64_t)ctx->num_cu * (uint64_t)std::max(1, std::min(per_cu, 32)));
+            hipLaunchKernelGGL(fill, dim3(g), dim3(64), 0, st, G);   // tasks come off the queue: any grid is correct
+            HIPC(ctx, hipGetLastError());
+            if (after_fill) HIPC(ctx, hipEventRecord(after_fill, st));
+            hipLaunchKernelGGL(walk_fn, dim3(G.n_pairs), dim3(64), 0, st, G);   // one wave per pair
+            HIPC(ctx, hipGetLastError());
+            return PWA_OK;
+        }
         HIPC(ctx, hipMemsetAsync(p_progress, 0, progress_bytes, st));
         if (!ctx->knobs.stamps.empty()) {
             HIPC(ctx, stamps.alloc(n_stripes * 32 + 4 * 8192 * 8));
@@ -1750,6 +1802,21 @@ int pwa_scores_affine(pwa_ctx* ctx, int match, int mismatch, int gap_open, int g
 // ------------------------------------------------------------------------- full alignments
 // Full alignments of a pair list.  With `ops` the op lists come back (pwa_align_batch); without, only the
 // per-pair scores and -- with `overlap_out` -- the overlap lengths computed by the walk itself (pwa_overlaps).
+//
+// Every pair gets the geometry ITS pattern asks for (r03; hw2.cpp:328-338: the reference's loop has no coupling between
+// pairs): patterns of up to 256 rows run on the mini-stripe engine (16 lanes per pair, RL = 4 .. 16 rows per lane: the
+// smallest RL that holds the pattern), longer ones on the stripe engine with their own (RL, W).  The list is cut into
+// RANGES of consecutive pairs whose bands fit the chunk budget; inside a range the pairs of each class form one launch
+// (fill + walk); the device op buffer mirrors the caller's regions of the whole range, so the op lists of all its classes
+// come back with one copy.
+namespace {
+struct TbClass {
+    bool mini;
+    int rl, w;   // mini: rows per lane (w unused); stripe engine: its PairGeom
+    bool operator==(const TbClass& o) const { return mini == o.mini && rl == o.rl && w == o.w; }
+};
+}  // namespace
+
 static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int gap, const uint8_t* seq_bytes,
                             const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
                             uint64_t n_pairs, int32_t* score_out, uint8_t* ops, const uint64_t* ops_off, uint64_t* n_ops,
@@ -1829,11 +1896,8 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     uint8_t* const arena_base = static_cast<uint8_t*>(p_arena);
     mark("arena upload");
 
-    uint64_t longest_n = 0, longest_sum = 0;
-    for (uint64_t k = 0; k < n_pairs; ++k) {
-        longest_n = std::max(longest_n, slen(pair_a[k]));
-        longest_sum = std::max(longest_sum, slen(pair_a[k]) + slen(pair_b[k]));
-    }
+    uint64_t longest_sum = 0;
+    for (uint64_t k = 0; k < n_pairs; ++k) longest_sum = std::max(longest_sum, slen(pair_a[k]) + slen(pair_b[k]));
     // scores x lengths beyond the packed keys' 2^28: the plain int32 form, exact for anything the reference's int holds
     const bool keyed = tb_range_ok(longest_sum, match, mismatch, gap) && !ctx->knobs.no_keyed_tb;
     // Global alignments with table scoring run in gap-shifted coordinates G = H - gap (i + j): the same recurrence with gap 0 and
@@ -1847,57 +1911,113 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         gap0 = km <= 127 && km >= -126 && kx <= 127 && kx >= -126 && (longest_sum + 2) <= (1ull << 27) / (uint64_t)amax;
     }
     const int k_match = gap0 ? match - 2 * gap : match, k_mismatch = gap0 ? mismatch - 2 * gap : mismatch, k_gap = gap0 ? 0 : gap;
-    const PairGeom geom = choose_geom(ctx->knobs, longest_n, keyed, true);
-    auto tb_band_bytes = [&](uint64_t n, uint64_t m) { return ::tb_band_bytes(n, m, geom.rl); };
-    // pairs are processed in chunks whose traceback bands fit the free HBM
+    // the mini-stripe engine exists for keyed cells with table scoring; PWA_FORCE_RL / PWA_FORCE_W address the stripe engine
+    const bool mini_ok = coded && keyed && ctx->knobs.tb_engine != 0 && !ctx->knobs.force_rl && !ctx->knobs.force_w;
+    auto class_of = [&](uint64_t n) -> TbClass {
+        if (mini_ok && n <= 256)
+            for (const int rl : kMiniRL)
+                if (n <= (uint64_t)(16 * rl)) return TbClass{true, rl, 1};
+        const PairGeom g = choose_geom(ctx->knobs, n, keyed, true);
+        return TbClass{false, g.rl, g.w};
+    };
+    // band bytes of a pair: the stripe engine's own; the mini-stripe engine's for a text of m_task columns (its task's longest)
+    auto band_of = [&](const TbClass& c, uint64_t n, uint64_t m_task) -> uint64_t {
+        if (c.mini) return (uint64_t)mini_band_steps(m_task) * 16 * (uint64_t)c.rl;
+        return ::tb_band_bytes(n, m_task, c.rl);
+    };
+
+    // ---- ranges of consecutive pairs whose traceback bands fit the free HBM
     size_t free_b = 0, total_b = 0;
     HIPC(ctx, hipMemGetInfo(&free_b, &total_b));
     const uint64_t budget = std::max<uint64_t>((uint64_t)(free_b * 0.8), 64ull << 20);
-    // A chunk's band is written once and read along one path per pair, so nothing is gained by a huge one, while
+    // A range's band is written once and read along one path per pair, so nothing is gained by a huge one, while
     // hipMalloc gets slow for very large requests ([gpu] profiles/r01_malloc_probe.txt: 0.3 ms up to 8 GiB,
-    // 0.24 s for 10.5 GB, >1 s for 16 GiB): chunks of <= 6 GiB of band (enough pairs to fill every CU; or one
-    // pair, whatever it needs), all using ONE allocation sized for the largest chunk.
+    // 0.24 s for 10.5 GB, >1 s for 16 GiB): ranges of <= 6 GiB of band (enough pairs to fill every CU; or one
+    // pair, whatever it needs), all using ONE allocation sized for the largest range.
     // (with the int32 score band on, that one is the large allocation: 2 GiB of codes + 8 GiB of scores)
     const uint64_t chunk_target = std::min<uint64_t>(budget, ctx->score_band ? (10ull << 30) : (6ull << 30));
-    struct Chunk {
-        uint64_t k0, k1, band, opsb;
-        bool tiled;      // the caller's op regions ops_off[k] .. + n_k + m_k of the chunk's pairs follow one another without a gap:
-        uint64_t span;   // the device op buffer then mirrors that range and comes back with ONE copy, straight into `ops`
+    const uint64_t band_mult = ctx->score_band ? 5 : 1;
+    struct Launch {                    // the pairs of one class inside one range
+        TbClass cls;
+        std::vector<uint32_t> q;       // pair index inside the range, in launch order (mini: longest text first)
+        std::vector<uint64_t> bo;      // band offset of each (bytes; the int32 score band uses the same offsets in elements)
+        std::vector<uint64_t> mt;      // mini: the text length the pair's band is sized for (its task's longest)
+        uint64_t dummy_bo[3] = {0, 0, 0};
+        uint32_t n_dummy = 0;
     };
-    std::vector<Chunk> chunks;
+    struct Range {
+        uint64_t k0, k1, band, opsb;
+        bool tiled;      // the caller's op regions ops_off[k] .. + n_k + m_k of the range's pairs follow one another without a gap:
+        uint64_t span;   // the device op buffer then mirrors that range and comes back with ONE copy, straight into `ops`
+        std::vector<Launch> launches;
+    };
+    std::vector<Range> ranges;
     uint64_t band_cap = 0, ops_cap_b = 0, nc_cap = 0;
     for (uint64_t k0 = 0; k0 < n_pairs;) {
-        uint64_t k1 = k0, band = 0, opsb = 0;
+        uint64_t k1 = k0, est = 0, opsb = 0;
         while (k1 < n_pairs) {
             const uint64_t n = slen(pair_a[k1]), m = slen(pair_b[k1]);
             if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
-            const uint64_t need = (n && m) ? align_up(tb_band_bytes(n, m), 256) : 0;
-            if (k1 > k0 && (band + need) * (ctx->score_band ? 5 : 1) + opsb + n + m > chunk_target) break;
-            band += need;
+            const uint64_t need = (n && m) ? align_up(band_of(class_of(n), n, m), 256) : 0;
+            if (k1 > k0 && (est + need) * band_mult + opsb + n + m > chunk_target) break;
+            est += need;
             opsb += align_up(n + m + 1, 16);
             ++k1;
         }
-        if (band * (ctx->score_band ? 5 : 1) + opsb > budget && band + opsb > (uint64_t)(free_b * 0.97))
+        Range rg{k0, k1, 0, opsb, want_ops, 0, {}};
+        // the range's launches: one per class present, pairs in caller order (mini: by text length, so that the four pairs of a
+        // wave run about the same number of steps; the band of each is sized for its task's longest text)
+        for (uint64_t k = k0; k < k1; ++k) {
+            const uint64_t n = slen(pair_a[k]), m = slen(pair_b[k]);
+            if (!(n && m)) continue;
+            const TbClass c = class_of(n);
+            size_t li = 0;
+            while (li < rg.launches.size() && !(rg.launches[li].cls == c)) ++li;
+            if (li == rg.launches.size()) {
+                rg.launches.emplace_back();
+                rg.launches.back().cls = c;
+            }
+            rg.launches[li].q.push_back((uint32_t)(k - k0));
+        }
+        uint64_t bo = 0;
+        for (Launch& L : rg.launches) {
+            const size_t np = L.q.size();
+            L.bo.resize(np);
+            if (L.cls.mini) {
+                std::stable_sort(L.q.begin(), L.q.end(), [&](uint32_t x, uint32_t y) { return slen(pair_b[k0 + x]) > slen(pair_b[k0 + y]); });
+                L.mt.resize(np);
+                for (size_t p = 0; p < np; ++p) L.mt[p] = slen(pair_b[k0 + L.q[p / 4 * 4]]);   // the task's first pair has its longest text
+                L.n_dummy = (uint32_t)((4 - np % 4) % 4);
+            }
+            for (size_t p = 0; p < np; ++p) {
+                L.bo[p] = bo;
+                bo += align_up(band_of(L.cls, slen(pair_a[k0 + L.q[p]]), L.cls.mini ? L.mt[p] : slen(pair_b[k0 + L.q[p]])), 256);
+            }
+            for (uint32_t d = 0; d < L.n_dummy; ++d) {   // the last task's empty patterns write their padding here
+                L.dummy_bo[d] = bo;
+                bo += align_up(band_of(L.cls, 0, L.mt[np - 1]), 256);
+            }
+        }
+        rg.band = bo;
+        if (rg.band * band_mult + opsb > budget && rg.band + opsb > (uint64_t)(free_b * 0.97))
             return fail(ctx, PWA_E_NOMEM, "traceback band of a single pair exceeds free HBM");
-        bool tiled = want_ops;
-        uint64_t span = 0;
         if (want_ops) {
             for (uint64_t k = k0; k < k1; ++k) {
                 const uint64_t cap = slen(pair_a[k]) + slen(pair_b[k]);
-                if (k + 1 < k1 && ops_off[k + 1] != ops_off[k] + cap) tiled = false;
-                span += cap;
+                if (k + 1 < k1 && ops_off[k + 1] != ops_off[k] + cap) rg.tiled = false;
+                rg.span += cap;
             }
-            if (ctx->knobs.no_tiled_ops) tiled = false;
+            if (ctx->knobs.no_tiled_ops) rg.tiled = false;
         }
-        chunks.push_back({k0, k1, band, opsb, tiled, span});
-        band_cap = std::max(band_cap, band);
-        ops_cap_b = std::max(ops_cap_b, std::max(opsb, tiled ? span + 16 : 0));
+        band_cap = std::max(band_cap, rg.band);
+        ops_cap_b = std::max(ops_cap_b, std::max(opsb, rg.tiled ? rg.span + 16 : 0));
         nc_cap = std::max(nc_cap, k1 - k0);
+        ranges.push_back(std::move(rg));
         k0 = k1;
     }
     DevBuf d_band, d_sband, d_ops_own, d_res_own;
     void *p_band = nullptr, *p_sband = nullptr, *p_ops = nullptr, *p_res = nullptr;
-    if (!chunks.empty()) {
+    if (!ranges.empty()) {
         // + one traceback window: the walk stages whole windows
         HIPC(ctx, cached_workspace(ctx->band_cache, ctx->band_cache_bytes, band_cap + 32768, d_band, &p_band));
         if (ctx->score_band)
@@ -1908,41 +2028,22 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     mark("band / ops allocation");
     uint8_t* const d_ops = static_cast<uint8_t*>(p_ops);
     PairResult* const d_res = static_cast<PairResult*>(p_res);
-    std::vector<uint8_t> host_ops;   // staging, only for chunks whose op regions do not tile
+    std::vector<uint8_t> host_ops;   // staging, only for ranges whose op regions do not tile
 
-    for (const Chunk& ch : chunks) {
-        const uint64_t k0 = ch.k0, k1 = ch.k1, band = ch.band, opsb = ch.opsb;
+    for (const Range& rg : ranges) {
+        const uint64_t k0 = rg.k0, k1 = rg.k1, opsb = rg.opsb;
         const uint64_t nc = k1 - k0;
-        PairLaunch pl;
-        pl.from_pool = true;
         HIPC(ctx, ctx->pin[pwa_ctx::PIN_RES].reserve(nc * sizeof(PairResult)));
         PairResult* const res = ctx->pin[pwa_ctx::PIN_RES].as<PairResult>();   // page-locked: uploaded, and read back after the walk
-        std::vector<PairDesc> pd;
         std::vector<uint64_t> ooff(nc);
-        uint64_t bo = 0, oo = 0;
+        uint64_t oo = 0;
         const uint64_t ops_lo = (want_ops && nc) ? ops_off[k0] : 0;
-        if (want_ops && !ch.tiled) host_ops.resize(opsb);
+        if (want_ops && !rg.tiled) host_ops.resize(opsb);
         for (uint64_t q = 0; q < nc; ++q) {
             const uint64_t k = k0 + q, n = slen(pair_a[k]), m = slen(pair_b[k]);
             std::memset(&res[q], 0, sizeof(PairResult));
-            ooff[q] = ch.tiled ? ops_off[k] - ops_lo : oo;
-            if (n && m) {
-                PairDesc d;
-                std::memset(&d, 0, sizeof d);
-                d.pat = arena_base + aoff[pair_a[k]];
-                d.txt = arena_base + aoff[pair_b[k]];
-                d.n = (int32_t)n;
-                d.m = (int32_t)m;
-                d.tb = static_cast<uint8_t*>(p_band) + bo;
-                if (ctx->score_band) d.sband = static_cast<int32_t*>(p_sband) + bo;
-                d.res = d_res + q;
-                d.ops = want_ops ? d_ops + ooff[q] : d_ops;   // WALK_OVERLAP never writes ops
-                d.ops_cap = (uint32_t)std::min<uint64_t>(n + m, 0xffffffffu);
-                d.score_bias = gap0 ? wrap_mul((int64_t)(n + m), gap) : 0;
-                pd.push_back(d);
-                bo += align_up(tb_band_bytes(n, m), 256);
-                ctx->band_bytes += tb_band_bytes(n, m) * (ctx->score_band ? 5 : 1);
-            } else if (!local) {
+            ooff[q] = rg.tiled ? ops_off[k] - ops_lo : oo;
+            if (!(n && m) && !local) {
                 res[q].score = wrap_mul((int64_t)(n + m), gap);
                 res[q].end_i = (uint32_t)n;
                 res[q].end_j = (uint32_t)m;
@@ -1950,17 +2051,47 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
             oo += align_up(n + m + 1, 16);
         }
         HIPC(ctx, hipMemcpy(d_res, res, nc * sizeof(PairResult), hipMemcpyHostToDevice));
-        mark("chunk descriptors");
-        if (!pd.empty()) {
+        mark("range results init");
+        for (const Launch& L : rg.launches) {
+            const size_t np = L.q.size();
+            std::vector<PairDesc> pd;
+            pd.reserve(np + L.n_dummy);
+            for (size_t p = 0; p < np; ++p) {
+                const uint64_t q = L.q[p], k = k0 + q, n = slen(pair_a[k]), m = slen(pair_b[k]);
+                PairDesc d;
+                std::memset(&d, 0, sizeof d);
+                d.pat = arena_base + aoff[pair_a[k]];
+                d.txt = arena_base + aoff[pair_b[k]];
+                d.n = (int32_t)n;
+                d.m = (int32_t)m;
+                d.tb = static_cast<uint8_t*>(p_band) + L.bo[p];
+                if (ctx->score_band) d.sband = static_cast<int32_t*>(p_sband) + L.bo[p];
+                d.res = d_res + q;
+                d.ops = want_ops ? d_ops + ooff[q] : d_ops;   // WALK_OVERLAP never writes ops
+                d.ops_cap = (uint32_t)std::min<uint64_t>(n + m, 0xffffffffu);
+                d.score_bias = gap0 ? wrap_mul((int64_t)(n + m), gap) : 0;
+                pd.push_back(d);
+                ctx->band_bytes += band_of(L.cls, n, L.cls.mini ? L.mt[p] : m) * band_mult;
+            }
+            for (uint32_t dmy = 0; dmy < L.n_dummy; ++dmy) {   // empty patterns that fill the last task: every cell of theirs is padding
+                PairDesc d = pd[np - 1];
+                d.n = 0;
+                d.tb = static_cast<uint8_t*>(p_band) + L.dummy_bo[dmy];
+                if (ctx->score_band) d.sband = static_cast<int32_t*>(p_sband) + L.dummy_bo[dmy];
+                pd.push_back(d);
+            }
+            PairLaunch pl;
+            pl.from_pool = true;
             pl.perm = coded && keyed;
             pl.keyed = keyed;
             pl.gap0 = gap0;
-            int rc = pl.build(ctx, pd, k_match, k_mismatch, k_gap, geom);
+            int rc = L.cls.mini ? pl.build_mini(ctx, pd, (uint32_t)np, k_match, k_mismatch, k_gap, L.cls.rl)
+                                : pl.build(ctx, pd, k_match, k_mismatch, k_gap, PairGeom{L.cls.rl, L.cls.w});
             if (rc != PWA_OK) return rc;
             pl.G.dash = dash_sym;
             mark("task list build + upload");
-            if (dbg) std::fprintf(stderr, "[pwa] fill launch grid=%u pairs=%u tasks=%u band=%llu rows=%llu\n", pl.grid,
-                                  pl.G.n_pairs, pl.G.n_tasks, (unsigned long long)band, (unsigned long long)pl.row_bytes);
+            if (dbg) std::fprintf(stderr, "[pwa] fill launch %s RL=%d W=%d grid=%u pairs=%u tasks=%u rows=%llu\n", L.cls.mini ? "mini" : "stripes", L.cls.rl,
+                                  L.cls.w, pl.grid, pl.G.n_pairs, pl.G.n_tasks, (unsigned long long)pl.row_bytes);
             HIPC(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
             rc = pl.launch(ctx, ctx->stream, local, true, want_ops ? WALK_OPS : WALK_OVERLAP, ctx->ev[1], ctx->score_band);
             if (rc != PWA_OK) return rc;
@@ -1976,8 +2107,8 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
             ctx->tb_ms += c;
         }
         HIPC(ctx, hipMemcpy(res, d_res, nc * sizeof(PairResult), hipMemcpyDeviceToHost));
-        if (want_ops && ch.tiled && ch.span) HIPC(ctx, hipMemcpy(ops + ops_lo, d_ops, ch.span, hipMemcpyDeviceToHost));   // straight into the caller's list
-        if (want_ops && !ch.tiled) HIPC(ctx, hipMemcpy(host_ops.data(), d_ops, opsb, hipMemcpyDeviceToHost));
+        if (want_ops && rg.tiled && rg.span) HIPC(ctx, hipMemcpy(ops + ops_lo, d_ops, rg.span, hipMemcpyDeviceToHost));   // straight into the caller's list
+        if (want_ops && !rg.tiled) HIPC(ctx, hipMemcpy(host_ops.data(), d_ops, opsb, hipMemcpyDeviceToHost));
         mark("results (+ ops) to host");
         if (dbg && want_ops) {   // the op-list walk leaves its LDS round trips in `overlap` (unused by that walk)
             uint64_t trips = 0, nops = 0;
@@ -1997,7 +2128,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
                 if (overlap_out) overlap_out[k] = 0;
             } else {
                 if (res[q].overflow) return fail(ctx, PWA_E_CAPACITY, "internal: traceback longer than n+m");
-                if (want_ops && !ch.tiled) std::memcpy(ops + ops_off[k], host_ops.data() + ooff[q], cnt);
+                if (want_ops && !rg.tiled) std::memcpy(ops + ops_off[k], host_ops.data() + ooff[q], cnt);
                 if (start_cells) {
                     start_cells[2 * k] = res[q].start_i;
                     start_cells[2 * k + 1] = res[q].start_j;
@@ -2079,17 +2210,44 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     }
     if (n == 0 || m == 0) return PWA_OK;
     HIPC(ctx, hipSetDevice(ctx->device));
-    const PairGeom geom = choose_geom(ctx->knobs, n, keyed, true);
+    // patterns of up to 256 rows over an alphabet of <= 7 symbols: the mini-stripe engine, as pwa_align_batch would pick it (so that
+    // the whole-matrix comparison covers that engine's cells too); everything else: the stripe engine on raw bytes
+    uint8_t code_of[256];
+    int n_alpha = 0;
+    {
+        bool seen[256] = {false};
+        for (uint64_t o = 0; o < n; ++o) seen[pattern[o]] = true;
+        for (uint64_t o = 0; o < m; ++o) seen[text[o]] = true;
+        for (int v = 0; v < 256; ++v) {
+            code_of[v] = (uint8_t)std::min(n_alpha, 7);
+            if (seen[v]) ++n_alpha;
+        }
+    }
+    const int64_t kd_match = ((int64_t)match - gap) * 4 + 2, kd_mismatch = ((int64_t)mismatch - gap) * 4 + 2;
+    const bool coded = n_alpha <= 7 && kd_match <= 127 && kd_match >= -126 && kd_mismatch <= 127 && kd_mismatch >= -126 && !ctx->knobs.no_pair_table;
+    int mini_rl = 0;
+    if (coded && keyed && n <= 256 && ctx->knobs.tb_engine != 0 && !ctx->knobs.force_rl && !ctx->knobs.force_w)
+        for (const int rl : kMiniRL)
+            if (!mini_rl && n <= (uint64_t)(16 * rl)) mini_rl = rl;
+    const PairGeom geom = mini_rl ? PairGeom{mini_rl, 1} : choose_geom(ctx->knobs, n, keyed, true);
     const uint64_t kRL = (uint64_t)geom.rl;
-    const uint64_t band = tb_band_bytes(n, m, geom.rl);
+    const uint64_t band = mini_rl ? (uint64_t)mini_band_steps(m) * 16 * kRL : tb_band_bytes(n, m, geom.rl);
     DevBuf d_pat, d_txt, d_band, d_sband, d_res;
     HIPC(ctx, d_pat.alloc(n + 64));
     HIPC(ctx, d_txt.alloc(m + 64));
-    HIPC(ctx, d_band.alloc(band + 32768));
-    HIPC(ctx, d_sband.alloc(band * sizeof(int32_t)));
+    HIPC(ctx, d_band.alloc((mini_rl ? 4 : 1) * band + 32768));
+    HIPC(ctx, d_sband.alloc((mini_rl ? 4 : 1) * band * sizeof(int32_t)));
     HIPC(ctx, d_res.alloc(sizeof(PairResult)));
-    HIPC(ctx, hipMemcpy(d_pat.p, pattern, n, hipMemcpyHostToDevice));
-    HIPC(ctx, hipMemcpy(d_txt.p, text, m, hipMemcpyHostToDevice));
+    if (mini_rl) {
+        std::vector<uint8_t> cp(n), ct(m);
+        for (uint64_t o = 0; o < n; ++o) cp[o] = code_of[pattern[o]];
+        for (uint64_t o = 0; o < m; ++o) ct[o] = code_of[text[o]];
+        HIPC(ctx, upload_via_bounce(ctx, d_pat.p, cp.data(), n));
+        HIPC(ctx, upload_via_bounce(ctx, d_txt.p, ct.data(), m));
+    } else {
+        HIPC(ctx, hipMemcpy(d_pat.p, pattern, n, hipMemcpyHostToDevice));
+        HIPC(ctx, hipMemcpy(d_txt.p, text, m, hipMemcpyHostToDevice));
+    }
     HIPC(ctx, hipMemset(d_res.p, 0, sizeof(PairResult)));
     std::vector<PairDesc> pd(1);
     std::memset(&pd[0], 0, sizeof(PairDesc));
@@ -2102,7 +2260,20 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     pd[0].res = d_res.as<PairResult>();
     PairLaunch pl;
     pl.keyed = keyed;
-    int rc = pl.build(ctx, pd, match, mismatch, gap, geom);
+    int rc;
+    if (mini_rl) {
+        for (int d = 1; d < 4; ++d) {   // three empty patterns fill the wave; their padding goes behind the pair's bands
+            PairDesc e = pd[0];
+            e.n = 0;
+            e.tb = d_band.as<uint8_t>() + (uint64_t)d * band;
+            e.sband = d_sband.as<int32_t>() + (uint64_t)d * band;
+            pd.push_back(e);
+        }
+        pl.perm = true;
+        rc = pl.build_mini(ctx, pd, 1, match, mismatch, gap, mini_rl);
+    } else {
+        rc = pl.build(ctx, pd, match, mismatch, gap, geom);
+    }
     if (rc != PWA_OK) return rc;
     rc = pl.launch(ctx, ctx->stream, local, true, false, nullptr, true);
     if (rc != PWA_OK) return rc;
@@ -2117,12 +2288,21 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     static const char kCodeNW[4] = {'u', 'l', 'd', 'd'}, kCodeSW[4] = {'l', 'u', 'd', '0'};   // hw2.cpp:145-153 / 214-222
     const char* const kCode = local ? kCodeSW : kCodeNW;
     const uint64_t T = band_steps(m);
+    const uint64_t PA = kRL >= 16 ? 16 : (kRL >= 8 ? 8 : 4), PB = kRL - PA;   // BandGeo<16, RL>
     for (uint64_t i = 1; i <= n; ++i) {
-        const uint64_t q = i - 1, st = q / (64 * kRL), k = (q % (64 * kRL)) / kRL, r = q % kRL;
+        const uint64_t q = i - 1;
         for (uint64_t j = 1; j <= m; ++j) {
-            const uint64_t idx = ((st * T + (j - 1 + k)) * 64 + k) * kRL + r;   // skewed band -> row-major matrix
+            uint64_t idx, sidx;   // skewed bands -> row-major matrix
+            if (mini_rl) {
+                const uint64_t k = q / kRL, r = q % kRL, t = j - 1 + k;
+                idx = t * 16 * kRL + (r < PA ? k * PA + r : 16 * PA + k * PB + (r - PA));
+                sidx = (t * 16 + k) * kRL + r;
+            } else {
+                const uint64_t st = q / (64 * kRL), k = (q % (64 * kRL)) / kRL, r = q % kRL;
+                idx = sidx = ((st * T + (j - 1 + k)) * 64 + k) * kRL + r;
+            }
             if (tb_out) tb_out[i * W + j] = kCode[hb[idx] & 3];
-            if (dp_out) dp_out[i * W + j] = hs[idx];
+            if (dp_out) dp_out[i * W + j] = hs[sidx];
         }
     }
     return PWA_OK;

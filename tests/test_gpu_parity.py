@@ -405,7 +405,7 @@ def test_scores_pass_is_routed_by_work(ctx):
     a list of many short pairs plus a few long ones is split, and results land in caller order whatever the split --
     scores against the oracle, both modes, and the same lists forced onto either engine."""
     rng = random.Random(303)
-    longs = [(O.gen(30, 0, i, 3000 + 500 * i), O.gen(30, 1, i, 3500 - 300 * i)) for i in range(3)]
+    longs = [(O.gen(30, 0, i, 1000 + 100 * i), O.gen(30, 1, i, 1200 - 100 * i)) for i in range(3)]   # ("long": 7+ register strips on one lane)
     shorts = [(O.gen(31, 0, i, rng.randint(20, 150)), O.gen(31, 1, i, rng.randint(100, 400))) for i in range(30000)]
 
     def lists():
@@ -640,21 +640,27 @@ def test_device_score_vector_in_caller_memory(sctx):
         b.close()
 
 
-def test_whole_matrices_match_reference_matrices(ctx):
+@pytest.mark.parametrize("engine", ["mini", "stripes"])
+def test_whole_matrices_match_reference_matrices(engine):
     """Every cell of the int32 score band and of the traceback band == the reference's `dp` and `traceback`
-    matrices (hw2.cpp:119-156 / 193-231), incl. row/column 0, several stripes, all scorings."""
+    matrices (hw2.cpp:119-156 / 193-231), incl. row/column 0, several stripes, all scorings.  "mini": patterns of up to 256 rows
+    through the mini-stripe engine (every RL class, lengths at both ends of each), longer ones through the stripe engine;
+    "stripes" (PWA_TB_ENGINE=0): everything through the stripe engine."""
     import numpy as np
     rng = random.Random(42)
     cases = [(1, 1), (3, 70), (70, 3), (255, 300), (256, 64), (257, 65), (600, 777), (1100, 90)]
-    for (n, m) in cases:
-        p = bytes(rng.choice(b"ACGT") for _ in range(n))
-        t = bytes(rng.choice(b"ACGT") for _ in range(m))
-        for sc in rng.sample(SCORINGS, 4):
-            for mode in ("nw", "sw"):
-                dp, tb = ctx.matrices(mode, p, t, *sc)
-                wdp, wtb = O.matrices(mode, p, t, *sc)
-                assert np.array_equal(dp, wdp), (mode, n, m, sc)
-                assert np.array_equal(tb, wtb), (mode, n, m, sc)
+    if engine == "mini":
+        cases += [(64, 100), (65, 31), (96, 200), (97, 16), (128, 129), (129, 15), (150, 333), (160, 47), (161, 48), (192, 17), (193, 250), (16, 1), (17, 500)]
+    with switched_context(**({"PWA_TB_ENGINE": "0"} if engine == "stripes" else {})) as c:
+        for (n, m) in cases:
+            p = bytes(rng.choice(b"ACGT") for _ in range(n))
+            t = bytes(rng.choice(b"ACGT") for _ in range(m))
+            for sc in rng.sample(SCORINGS, 4):
+                for mode in ("nw", "sw"):
+                    dp, tb = c.matrices(mode, p, t, *sc)
+                    wdp, wtb = O.matrices(mode, p, t, *sc)
+                    assert np.array_equal(dp, wdp), (mode, n, m, sc)
+                    assert np.array_equal(tb, wtb), (mode, n, m, sc)
 
 
 def test_scores_degenerate_shapes(sctx):
@@ -868,13 +874,18 @@ def test_one_shot_calls_cut_oversized_pair_lists_into_arena_chunks(ctx):
         assert c.scores_affine_oneshot(seqs, pa, pb, 5, -4, -16, -4) == whole_a == [O.affine_score(seqs[a], seqs[b], 5, -4, -16, -4) for a, b in zip(pa, pb)]
 
 
-@pytest.mark.parametrize("n_class", [(1, 63, 64), (65, 127, 128), (129, 200, 256), (257, 300, 511, 512, 513), (700, 1025, 1100, 1537)])
-def test_pair_engine_shapes_around_every_boundary(n_class):
+@pytest.mark.parametrize("engine,n_class", [("stripes", (1, 63, 64)), ("stripes", (65, 127, 128)), ("stripes", (129, 200, 256)),
+                                            ("stripes", (257, 300, 511, 512, 513)), ("stripes", (700, 1025, 1100, 1537)),
+                                            ("mini", (1, 15, 16, 17, 63, 64)), ("mini", (65, 95, 96, 97, 127, 128)),
+                                            ("mini", (129, 150, 159, 160, 161)), ("mini", (191, 192, 193, 255, 256, 257))])
+def test_pair_engine_shapes_around_every_boundary(engine, n_class):
     """The written-out fill chunks (r02): pattern lengths around stripe / workgroup boundaries x text lengths around hand-off chunks
     (16 steps), the lane ramp (63 steps) and the LDS ring (512 columns), for both modes, table and compare scoring, gap-shifted and
-    plain global form, with and without the score band -- every op list, end and start cell against the oracle.  All pairs of one
-    n-class go through ONE batch so that they share a geometry (RL, W) and run concurrently."""
-    rng = random.Random(hash(n_class) & 0xffff)
+    plain global form, with and without the score band -- every op list, end and start cell against the oracle.  "stripes": all
+    pairs on the stripe engine (PWA_TB_ENGINE=0; one n-class = one geometry).  "mini" (r03): pattern lengths around every row
+    class of the mini-stripe engine (16 RL rows, RL = 4 .. 16) and its 15-step lane ramp; the pairs of one call then fall into
+    several geometry classes -- several launches -- and the longest (257) onto the stripe engine."""
+    rng = random.Random(sum(n_class) * 7 + len(n_class))
     ms = [1, 2, 15, 16, 17, 31, 47, 48, 49, 62, 63, 64, 65, 79, 80, 81, 95, 127, 128, 129, 191, 255, 256, 257, 511, 512, 513, 520, 1030]
     seqs, pa, pb = [], [], []
     for n in n_class:
@@ -887,6 +898,8 @@ def test_pair_engine_shapes_around_every_boundary(n_class):
             pb.append(len(seqs) - 1)
     variants = [({}, False), ({"PWA_NO_GAP_SHIFT": "1"}, False), ({"PWA_NO_PAIR_TABLE": "1"}, False), ({}, True)]
     for env, band in variants:
+        if engine == "stripes":
+            env = dict(env, PWA_TB_ENGINE="0")
         with switched_context(**env) as c:
             c.set_score_band(band)
             for mode in ("nw", "sw"):
@@ -896,6 +909,57 @@ def test_pair_engine_shapes_around_every_boundary(n_class):
                         want = O.align(mode, seqs[pa[k]], seqs[pb[k]], *sc, compact=True)
                         assert (r["score"], r["ops"], tuple(r["end"]), tuple(r["start"])) == \
                             (want["score"], want["ops"], tuple(want["end"]), tuple(want["start"])), (env, band, mode, sc, len(seqs[pa[k]]), len(seqs[pb[k]]))
+
+
+def test_every_pair_gets_its_own_geometry(ctx):
+    """r03: pwa_align_batch / pwa_overlaps choose the band geometry pair by pair -- one 40 kb pattern in a list
+    of 100-row patterns no longer turns every short pair into a 256-row stripe.  One call with a 40 000-row pattern (stripe engine,
+    RL = 4), 600-row ones (RL = 2), and 2000 patterns of ~100 rows (mini-stripe engine, two RL classes), interleaved: op lists,
+    end / start cells, scores and overlaps against the oracle, in caller order."""
+    rng = random.Random(40000)
+    big_p = O.gen(40, 0, 0, 40000)
+    big_t = _mutate(rng, big_p[5000:5900], 0.1)
+    seqs, pa, pb = [], [], []
+
+    def add(p, t):
+        seqs.extend([p, t])
+        pa.append(len(seqs) - 2)
+        pb.append(len(seqs) - 1)
+
+    for k in range(2000):
+        p = O.gen(41, 0, k, rng.randint(60, 130))
+        add(p, _mutate(rng, p, 0.15) + O.gen(41, 1, k, rng.randint(0, 300)))
+        if k == 700:
+            add(big_p, big_t)
+        if k % 400 == 7:
+            p6 = O.gen(42, 0, k, 600 + k % 50)
+            add(p6, _mutate(rng, p6, 0.1))
+    for mode in ("nw", "sw"):
+        res = ctx.align_batch(mode, seqs, pa, pb, 1, -1, -1)
+        scores, ovl = ctx.overlaps(mode, seqs, pa, pb, 1, -1, -1)
+        for k, r in enumerate(res):
+            want = O.align(mode, seqs[pa[k]], seqs[pb[k]], 1, -1, -1, compact=True)
+            assert (r["score"], r["ops"], tuple(r["end"]), tuple(r["start"])) == \
+                (want["score"], want["ops"], tuple(want["end"]), tuple(want["start"])), (mode, k, len(seqs[pa[k]]), len(seqs[pb[k]]))
+            assert (scores[k], ovl[k]) == (want["score"], want["overlap"]), (mode, k)
+
+
+@pytest.mark.parametrize("how", ["padded regions", "PWA_NO_TILED_OPS"])
+def test_op_lists_through_the_staging_copy(how):
+    """pwa_align_batch with op regions that do NOT follow one another without a gap (a C caller with aligned regions), and with the
+    tiled fast path switched off: the op lists come back through the staging copy and must equal the tiled result and the oracle.
+    (Bytes of a region beyond n_ops[k] are undefined, include/pwalign.h.)"""
+    rng = random.Random(1813)
+    seqs = [bytes(rng.choice(b"ACGT") for _ in range(rng.choice([0, 1, 50, 150, 300, 700]))) for _ in range(40)]
+    pa = [rng.randrange(40) for _ in range(120)]
+    pb = [rng.randrange(40) for _ in range(120)]
+    with switched_context(**({"PWA_NO_TILED_OPS": "1"} if how != "padded regions" else {})) as c:
+        for mode in ("nw", "sw"):
+            res = c.align_batch(mode, seqs, pa, pb, 2, -3, -5, region_pad=16 if how == "padded regions" else 0)
+            for k, r in enumerate(res):
+                want = O.align(mode, seqs[pa[k]], seqs[pb[k]], 2, -3, -5, compact=True)
+                assert (r["score"], r["ops"], tuple(r["end"]), tuple(r["start"])) == \
+                    (want["score"], want["ops"], tuple(want["end"]), tuple(want["start"])), (how, mode, k)
 
 
 def _indel_blocks(rng, s, n_events, max_len):
