@@ -284,6 +284,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c3i", "c4", "c2", "c2b", "c5", "hw3", "hw4", "g", "gb"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plen", type=int, default=150, help="pattern length of the g / gb workloads (150 = the C3 shape)")
+    ap.add_argument("--pairs", type=int, default=0, help="g / gb: pairs per GPU (default 4096; other values are experiments, the line says so)")
     ap.add_argument("--nw", action="store_true", help="c3i: global (NW) instead of local scores")
     ap.add_argument("--small", action="store_true", help="reduced sizes (functional check only; line is marked invalid)")
     ap.add_argument("--rehearse-cpu", action="store_true",
@@ -577,7 +578,7 @@ def bench_global_batch(args, pkg, ctx, rank=0, world=1, dist=None, torch=None, d
     """The `-g` shape: FULL alignments (fill + traceback band + walk) of many index-paired short patterns x long
     texts (hw2.cpp:328-338 with global = true).  N > 1: the pair list of 4096 N pairs is dealt in contiguous blocks of
     4096 (weak scaling: every rank its own patterns), one all-gather of the per-pair scores and op counts per step."""
-    n_pairs = (8 if cpu else 256) if args.small else 4096
+    n_pairs = (8 if cpu else 256) if args.small else (args.pairs or 4096)
     tlen, n_txt = (200, 4) if cpu else (10000, 256)
     bands = args.workload == "gb"   # gb: Smith-Waterman with the int32 score band ALSO written (5 B/cell, SURVEY.md 8d)
     mode = "sw" if bands else "nw"

@@ -31,6 +31,11 @@ namespace pwa {
 // band steps of a mini-stripe pair whose task's longest text has m columns: m + 15 anti-diagonal steps in whole 16-step chunks
 __host__ __device__ inline size_t mini_band_steps(size_t m) { return (m + 15 + 15) & ~(size_t)15; }
 
+#ifdef PWA_BAND_STORE_NT   // experiment builds: non-temporal band stores
+#define PWA_BAND_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define PWA_BAND_STORE(ptr, val) (*(ptr) = (val))
+#endif
 typedef uint32_t mu32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t mu32x4 __attribute__((ext_vector_type(4)));
 
@@ -97,24 +102,37 @@ __device__ __forceinline__ void mini_chunk(const int t0, const int k, const int 
         bottom = act ? up : bottom;
         tch = tn;
         // the step's codes: plane A (PA bytes per lane), plane B (PB bytes per lane)
-        if constexpr (Geo::PA == 4) *(g_u32*)(tba + q * Geo::SR) = codes[0];
-        if constexpr (Geo::PA == 8) *(PWA_GLOBAL mu32x2*)(tba + q * Geo::SR) = mu32x2{codes[0], codes[1]};
-        if constexpr (Geo::PA == 16) *(PWA_GLOBAL mu32x4*)(tba + q * Geo::SR) = mu32x4{codes[0], codes[1], codes[2], codes[3]};
-        if constexpr (Geo::PB == 2) *(PWA_GLOBAL uint16_t*)(tbb + q * Geo::SR) = (uint16_t)codes[Geo::PA / 4];
-        if constexpr (Geo::PB == 4) *(g_u32*)(tbb + q * Geo::SR) = codes[Geo::PA / 4];
+#ifdef PWA_MINI_NOSTORE   // timing-only experiment builds (results are wrong): what the fill costs without its band stores
+        if (t0 == 0x7ffffff0)
+#endif
+        {
+        if constexpr (Geo::PA == 4) PWA_BAND_STORE((g_u32*)(tba + q * Geo::SR), codes[0]);
+        if constexpr (Geo::PA == 8) PWA_BAND_STORE((PWA_GLOBAL mu32x2*)(tba + q * Geo::SR), (mu32x2{codes[0], codes[1]}));
+        if constexpr (Geo::PA == 16) PWA_BAND_STORE((PWA_GLOBAL mu32x4*)(tba + q * Geo::SR), (mu32x4{codes[0], codes[1], codes[2], codes[3]}));
+        if constexpr (Geo::PB == 2) PWA_BAND_STORE((PWA_GLOBAL uint16_t*)(tbb + q * Geo::SR), (uint16_t)codes[Geo::PA / 4]);
+        if constexpr (Geo::PB == 4) PWA_BAND_STORE((g_u32*)(tbb + q * Geo::SR), codes[Geo::PA / 4]);
         if (SBAND) {
 #pragma unroll
             for (int r = 0; r < RL; ++r) sb[q * Geo::SR + r] = hsb[r];
         }
+        }
     });
 }
 
+// A workgroup = FOUR waves, each running its own tasks -- four only so that the launch can be balanced: the host asks for as much (unused)
+// dynamic LDS per workgroup as leaves room for exactly ceil(workgroups / CUs) of them on a CU, and the four waves of a workgroup go to
+// the CU's four SIMDs.  [gpu, r03: tools/probes/simd_place2.hip] Launched as 1024 single-wave workgroups, the same kernel took 1.35 ms
+// after an idle GPU or after itself, but 2.4 ms whenever another kernel (the walk, a copy kernel, any large grid) had run before it:
+// the dispatcher then starts somewhere else in its round-robin and doubles waves up on some SIMDs while others stay empty -- and a
+// wave that runs one 1.3 ms task cannot be rebalanced.
+constexpr int kMiniWaves = 4;
 template <int RL, bool LOCAL, bool SBAND, bool GAP0>
-__global__ __launch_bounds__(64) void mini_fill_kernel(const PairParams G) {
+__global__ __launch_bounds__(64 * kMiniWaves) void mini_fill_kernel(const PairParams G) {
     typedef BandGeo<16, RL> Geo;
     constexpr int NQ = (RL + 3) / 4;
     constexpr int PU = TbCode<LOCAL>::UP, PL = TbCode<LOCAL>::LEFT;
-    const int lane = threadIdx.x, k = lane & 15, grp = lane >> 4;
+    const int lane = threadIdx.x & 63, k = lane & 15, grp = lane >> 4;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int match = G.match, mismatch = G.mismatch, gap = G.gap;
     // key constants (pair_fill.hip.h): diagonal (s - gap) * 4 + (prio(diag) - prio(left)), left gap * 4 + prio(left); as a byte table
     const int a_match = (int)(((unsigned)match - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - PL));
@@ -122,15 +140,9 @@ __global__ __launch_bounds__(64) void mini_fill_kernel(const PairParams G) {
     const int cl = (int)((unsigned)gap * 4u + (unsigned)PL);
     const uint32_t bm = (uint32_t)(uint8_t)(int8_t)a_match, bx = (uint32_t)(uint8_t)(int8_t)a_mismatch;
     const uint32_t tab_lo = bm | (bx << 8) | (bx << 16) | (bx << 24), tab_hi = bx * 0x01010101u;   // selector 0 -> match, 1..7 -> mismatch
-    for (;;) {
-        uint32_t tid = 0;
-        {
-            int elect = lane;   // opaque electing lane: see batch_scores.hip.h
-            asm volatile("" : "+v"(elect));
-            if (elect == 0) tid = atomicAdd(G.queue, 1u);
-        }
-        tid = __builtin_amdgcn_readfirstlane(tid);
-        if (tid >= G.n_tasks) break;
+    // Tasks are dealt statically: wave w of workgroup b runs tasks 4 b + w, 4 (b + grid) + w, ... (the host sorts them longest first; all
+    // tasks of a round are about equally long, and a queue could not move a 1.3 ms task anyway).
+    for (uint32_t tid = blockIdx.x * kMiniWaves + wave; tid < G.n_tasks; tid += gridDim.x * kMiniWaves) {
         // this row's pair (the host pads the descriptor list to whole tasks with empty patterns on a dump band)
         const PWA_GLOBAL PairDesc* const P = (const PWA_GLOBAL PairDesc*)(G.pairs + (size_t)tid * 4 + grp);
         const int n = P->n, m = P->m;

@@ -778,6 +778,9 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
 // window the window before it is already in flight into the second LDS buffer.  The walk state
 // is wave-uniform and lives in SGPRs; the only per-op latency left is one ds_read_u8.
 enum { WALK_NONE = 0, WALK_OPS = 1, WALK_OVERLAP = 2 };   // end cells only / op list / overlap length, no op list
+#ifndef PWA_WALK_LOAD_AUX
+#define PWA_WALK_LOAD_AUX 0   // cache-policy bits of the walk's band loads (gfx94x: sc0 = 1, nt = 2, sc1 = 16)
+#endif
 
 // Where the code of a cell sits inside its band, for the two band geometries:
 //   LN = 64  the stripe engine above: a stripe = 64 lanes x RL rows, one step = 64 RL bytes [lane][RL];
@@ -857,15 +860,15 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         for (int u = 0; u < WB / 4096; ++u) {
             const PWA_GLOBAL uint32_t* g = (const PWA_GLOBAL uint32_t*)(tb + off0 + (size_t)u * 4096 + lane * 16);
             __attribute__((address_space(3))) uint32_t* l = (__attribute__((address_space(3))) uint32_t*)(win + buf * WB + u * 4096);
-            __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
-            __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
-            __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 0, PWA_WALK_LOAD_AUX);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 1024, PWA_WALK_LOAD_AUX);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 2048, PWA_WALK_LOAD_AUX);
+            __builtin_amdgcn_global_load_lds(g, l, 16, 3072, PWA_WALK_LOAD_AUX);
         }
 #pragma unroll
         for (int u = (WB / 4096) * 4; u < WB / 1024; ++u)   // (RL = 2: 8 KiB windows are whole multiples of 4 KiB as well; nothing left)
             __builtin_amdgcn_global_load_lds((const PWA_GLOBAL uint32_t*)(tb + off0 + (size_t)u * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) uint32_t*)(win + buf * WB + u * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) uint32_t*)(win + buf * WB + u * 1024), 16, 0, PWA_WALK_LOAD_AUX);
     };
     // ---- the walk.  Per trip the 64 lanes look at the 64 cells of the DIAGONAL through (i, j):
     // lane d reads the code of (i-d, j-d).  The leading run of 'd' codes is one run of 'M' ops,

@@ -135,7 +135,7 @@ struct pwa_ctx {
     enum { PIN_ARENA, PIN_ARENA2, PIN_TASKS, PIN_SLOT0, PIN_SLOT1, PIN_SLOT2, PIN_SLOT3, PIN_SLOT4, PIN_DESC, PIN_TL, PIN_RES, PIN_BOUNCE, PIN_N };
     PinnedBuf pin[PIN_N];
 };
-constexpr size_t kBandCacheMax = 24ull << 30;
+constexpr size_t kBandCacheMax = 64ull << 30;   // (288 GB of HBM per GPU: a 4096-pair batch with both bands is 33 GB)
 
 namespace {
 
@@ -504,10 +504,18 @@ struct PairLaunch {
             const pair_kernel_t fill = mini_fill_kernel_for(geom.rl, local, sband, gap0 && !sband && !local);
             const pair_kernel_t walk_fn = mini_traceback_kernel_for(geom.rl, local, walk);
             if (!fill || !walk_fn || !tb || !perm || !keyed) return fail(ctx, PWA_E_INVALID, "internal: no mini-stripe kernel for this form");
-            int per_cu = 0;
-            HIPC(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fill), 64, 0));
-            const uint32_t g = (uint32_t)std::min<uint64_t>(G.n_tasks, (uint64_t)ctx->num_cu * (uint64_t)std::max(1, std::min(per_cu, 32)));
-            hipLaunchKernelGGL(fill, dim3(g), dim3(64), 0, st, G);   // tasks come off the queue: any grid is correct
+            // Workgroups of four waves (one task each per round); `per_cu` of them per CU, enforced through the dynamic LDS request, so
+            // that no CU gets more than its share whatever ran before (mini_fill.hip.h): with ceil(tasks / 4) workgroups for 256 CUs,
+            // per_cu = ceil(workgroups / CUs), at most 2; longer task lists run in rounds ([gpu] pairs 150 x 10k: 8192 of them at two
+            // waves per SIMD 2.68 ms, 16384 at four 6.61 ms -- 16 k concurrent write streams get 4.0 instead of 4.9 TB/s out of HBM).
+            const uint32_t n_wg = (G.n_tasks + kMiniWaves - 1) / kMiniWaves;
+            const uint32_t per_cu = std::min<uint32_t>(2, (n_wg + (uint32_t)ctx->num_cu - 1) / (uint32_t)ctx->num_cu);
+            static const uint32_t kPadKiB[6] = {0, 96, 64, 48, 36, 30};   // more than 160 KiB / (per_cu + 1), at most 160 KiB / per_cu
+            const size_t pad_lds = (size_t)kPadKiB[per_cu] * 1024;
+            HIPC(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds));
+            const uint32_t g = std::min<uint32_t>(n_wg, (uint32_t)ctx->num_cu * per_cu);
+            if (ctx->knobs.debug) std::fprintf(stderr, "[pwa] mini fill: %u tasks, %u workgroups of %d waves, %u per CU (%zu KiB of LDS each)\n", G.n_tasks, g, kMiniWaves, per_cu, pad_lds >> 10);
+            hipLaunchKernelGGL(fill, dim3(g), dim3(64 * kMiniWaves), pad_lds, st, G);
             HIPC(ctx, hipGetLastError());
             if (after_fill) HIPC(ctx, hipEventRecord(after_fill, st));
             hipLaunchKernelGGL(walk_fn, dim3(G.n_pairs), dim3(64), 0, st, G);   // one wave per pair
@@ -1935,8 +1943,30 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     // 0.24 s for 10.5 GB, >1 s for 16 GiB): ranges of <= 6 GiB of band (enough pairs to fill every CU; or one
     // pair, whatever it needs), all using ONE allocation sized for the largest range.
     // (with the int32 score band on, that one is the large allocation: 2 GiB of codes + 8 GiB of scores)
-    const uint64_t chunk_target = std::min<uint64_t>(budget, ctx->score_band ? (10ull << 30) : (6ull << 30));
+    // [gpu, r03] But a range is a launch of its own, and a launch takes at least the time ONE wave needs for its longest pair (1.3 ms
+    // for a 10k-column text on the mini-stripe engine, whatever the number of pairs): the 4096 x (150 x 10k) batch -- 6.56 GB of
+    // band, just over 6 GiB -- ran as 4020 + 76 pairs in 2 x 1.3 ms, and with the score band (32.8 GB) as four launches of 256
+    // waves on a chip of 1024 SIMDs.  So: a range should hold ~8192 pairs where the list has them (2048+ waves), it may use up to
+    // 48 GiB for that (the workspace is kept in the context: the slow hipMalloc is paid once), and a list that needs several ranges is
+    // cut into EQUAL ones, not into full ones and a remainder.
     const uint64_t band_mult = ctx->score_band ? 5 : 1;
+    uint64_t chunk_target = std::min<uint64_t>(budget, 8ull << 30);
+    {
+        uint64_t total = 0, live = 0;
+        for (uint64_t k = 0; k < n_pairs; ++k) {
+            const uint64_t n = slen(pair_a[k]), m = slen(pair_b[k]);
+            if (!(n && m) || n > 0x7fffffc0ull || m > 0x7fffffc0ull) continue;
+            total += align_up(band_of(class_of(n), n, m), 256) * band_mult + align_up(n + m + 1, 16);
+            ++live;
+        }
+        if (live) {
+            const uint64_t cap = std::min<uint64_t>(budget, 48ull << 30);
+            const uint64_t for_8192 = (uint64_t)((long double)total / (long double)live * 8192.0L);
+            chunk_target = std::min<uint64_t>(cap, std::max<uint64_t>(chunk_target, for_8192));
+            const uint64_t n_ranges = (total + chunk_target - 1) / chunk_target;
+            if (n_ranges > 1) chunk_target = std::min<uint64_t>(cap, total / n_ranges + total / live + (1ull << 20));   // equal shares (+ one average pair)
+        }
+    }
     struct Launch {                    // the pairs of one class inside one range
         TbClass cls;
         std::vector<uint32_t> q;       // pair index inside the range, in launch order (mini: longest text first)
