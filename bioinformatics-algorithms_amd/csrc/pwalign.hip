@@ -71,6 +71,7 @@ struct Knobs {
     bool no_keyed_tb = false;                   // PWA_NO_KEYED_TB: traceback fills in the plain int32 form
     bool no_gap_shift = false;                  // PWA_NO_GAP_SHIFT: global traceback fills in H, not G = H - gap (i + j)
     bool no_tiled_ops = false;                  // PWA_NO_TILED_OPS: op lists through the staging copy
+    bool no_pipeline = false;                   // PWA_NO_PIPELINE: one-shot score calls are not cut into pipelined runs (only at 4 GiB of sequences)
     int scores_route = -1;                      // PWA_SCORES_ROUTE: 0 = every pair on the strip engine, 1 = every pair on the stripe
                                                 // engine, unset = by estimated cost (batch_create_impl)
     int tb_engine = -1;                         // PWA_TB_ENGINE: 0 = stripe engine only, 1 = mini-stripe engine wherever it applies,
@@ -97,6 +98,7 @@ struct Knobs {
         no_keyed_tb = flag("PWA_NO_KEYED_TB");
         no_gap_shift = flag("PWA_NO_GAP_SHIFT");
         no_tiled_ops = flag("PWA_NO_TILED_OPS");
+        no_pipeline = flag("PWA_NO_PIPELINE");
         scores_route = num("PWA_SCORES_ROUTE", -1);
         tb_engine = num("PWA_TB_ENGINE", -1);
     }
@@ -132,6 +134,12 @@ struct pwa_ctx {
     // page-locked staging of everything the library itself uploads or reads back (see PinnedBuf)
     hipStream_t copy_stream = nullptr;                 // uploads that overlap host work (build_arena)
     hipEvent_t copy_ev[2] = {nullptr, nullptr};
+    // Device buffers of destroyed batch objects, kept for the next one (DevBuf below): a steady stream of batches -- the runs of a
+    // one-shot call over a large list, a caller that builds batch after batch -- costs no hipMalloc and, more to the point, no
+    // hipFree: hipFree waits for ALL work on the device, i.e. for the kernels of the batch that is still running, and with it the
+    // overlap of preparing run k + 1 with computing run k would be gone (scores_in_arena_chunks).
+    std::vector<std::pair<void*, size_t>> free_list;
+    size_t free_list_bytes = 0;
     enum { PIN_ARENA, PIN_ARENA2, PIN_TASKS, PIN_SLOT0, PIN_SLOT1, PIN_SLOT2, PIN_SLOT3, PIN_SLOT4, PIN_DESC, PIN_TL, PIN_RES, PIN_BOUNCE, PIN_N };
     PinnedBuf pin[PIN_N];
 };
@@ -139,22 +147,52 @@ constexpr size_t kBandCacheMax = 64ull << 30;   // (288 GB of HBM per GPU: a 409
 
 namespace {
 
-struct DevBuf {   // RAII device allocation
+constexpr size_t kFreeListMaxBytes = 24ull << 30, kFreeListMaxCount = 64;
+struct DevBuf {   // RAII device allocation; with `pool` set, released buffers go to the context's free list and come back from it
     void* p = nullptr;
     size_t bytes = 0;
+    pwa_ctx* pool = nullptr;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (pool && pool->free_list.size() < kFreeListMaxCount && pool->free_list_bytes + bytes <= kFreeListMaxBytes) {
+                pool->free_list.emplace_back(p, bytes);
+                pool->free_list_bytes += bytes;
+            } else {
+                (void)hipFree(p);
+            }
+        }
         p = nullptr;
         bytes = 0;
     }
     hipError_t alloc(size_t n) {
         release();
         if (n == 0) n = 16;
+        if (pool) {   // best fit among the kept buffers: at least n, at most 2 n + 1 MiB (a 5 GB block is not spent on a 1 KB request)
+            size_t best = pool->free_list.size();
+            for (size_t i = 0; i < pool->free_list.size(); ++i) {
+                const size_t have = pool->free_list[i].second;
+                if (have >= n && have <= 2 * n + (1u << 20) && (best == pool->free_list.size() || have < pool->free_list[best].second)) best = i;
+            }
+            if (best < pool->free_list.size()) {
+                p = pool->free_list[best].first;
+                bytes = pool->free_list[best].second;
+                pool->free_list_bytes -= bytes;
+                pool->free_list.erase(pool->free_list.begin() + (long)best);
+                return hipSuccess;
+            }
+        }
         hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess && pool && !pool->free_list.empty()) {   // out of memory with buffers parked: give them back and try again
+            for (auto& f : pool->free_list) (void)hipFree(f.first);
+            pool->free_list.clear();
+            pool->free_list_bytes = 0;
+            (void)hipGetLastError();
+            e = hipMalloc(&p, n);
+        }
         if (e == hipSuccess) bytes = n;
         else p = nullptr;
         return e;
@@ -669,6 +707,7 @@ void pwa_ctx_destroy(pwa_ctx* c) {
     if (c->hand_cache) (void)hipFree(c->hand_cache);
     for (void* q : c->pool)
         if (q) (void)hipFree(q);
+    for (auto& f : c->free_list) (void)hipFree(f.first);
     delete c;
 }
 
@@ -720,6 +759,9 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         ~Guard() { if (b) pwa_batch_destroy(b); }
     } guard{b};
     b->ctx = ctx;
+    for (DevBuf* d : {&b->arena, &b->tasks, &b->slot_poff, &b->slot_plen, &b->slot_out, &b->slot_toff, &b->slot_tlen, &b->lane_text, &b->hand, &b->queue,
+                      &b->scores, &b->pair_res, &b->pl.desc, &b->pl.tasks, &b->pl.rows, &b->pl.progress, &b->pl.best, &b->pl.queue})
+        d->pool = ctx;   // released buffers are kept for the next batch of this context
     b->mode = mode;
     b->n_pairs = n_pairs;
     b->want_end = want_end_cells != 0;
@@ -764,9 +806,10 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
 
     HIPC(ctx, b->scores.alloc(std::max<uint64_t>(n_pairs, 1) * sizeof(int32_t)));
     if (any_trivial_score) HIPC(ctx, upload_via_bounce(ctx, b->scores.p, b->host_scores.data(), n_pairs * sizeof(int32_t)));
-    else {   // (on the context's stream and waited for: a run may be enqueued on any stream afterwards)
-        HIPC(ctx, hipMemsetAsync(b->scores.p, 0, std::max<uint64_t>(n_pairs, 1) * sizeof(int32_t), ctx->stream));
-        HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    else {   // (on the copy stream and waited for: a run may be enqueued on any stream afterwards -- and the context's own stream may be
+             // busy with the previous batch's run, which preparing this one must not wait for)
+        HIPC(ctx, hipMemsetAsync(b->scores.p, 0, std::max<uint64_t>(n_pairs, 1) * sizeof(int32_t), ctx->copy_stream));
+        HIPC(ctx, hipStreamSynchronize(ctx->copy_stream));
     }
     HIPC(ctx, b->queue.alloc(64));   // (the event ring of the runs is created run by run: pwa_batch_run)
     if (live.empty()) {
@@ -1733,20 +1776,54 @@ static uint64_t arena_limit(const pwa_ctx* ctx) {
     if (ctx->knobs.arena_limit) return ctx->knobs.arena_limit;   // tests
     return 0xffffffffull - (1ull << 20);
 }
+// r03 (overlap H2D with compute): the runs are PIPELINED -- while the kernels of run k execute, run k + 1 is validated,
+// scheduled, coded and uploaded (copy stream, page-locked pieces) and its kernels are queued behind; the host then collects run k.
+// And a list whose sequences exceed ~100 MB is cut into runs on purpose (about six), although one arena would hold it, so that the
+// first kernels start when a sixth of the input is on the device instead of all of it.  Destroyed runs hand their device buffers
+// to the context's free list (no hipFree: it would wait for the run in flight).
 template <class Create>
 static int scores_in_arena_chunks(pwa_ctx* ctx, const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
                                   uint64_t n_pairs, int32_t* score_out, uint32_t* end_i_out, uint32_t* end_j_out, Create&& create) try {
     if (!seq_off || (n_pairs && (!pair_a || !pair_b))) return fail(ctx, PWA_E_INVALID, "null input");
-    const uint64_t limit = arena_limit(ctx);
+    uint64_t limit = arena_limit(ctx);
     std::vector<uint64_t> stamp(n_seq, 0);
-    uint64_t k0 = 0, chunk = 0;
-    do {
+    uint64_t chunk = 0;
+    if (!ctx->knobs.arena_limit && !ctx->knobs.no_pipeline) {   // arena bytes of the whole list: is it worth cutting for the pipeline?
         ++chunk;
+        uint64_t total = 512;
+        for (uint64_t k = 0; k < n_pairs; ++k)
+            for (const uint32_t sidx : {pair_a[k], pair_b[k]}) {
+                if (sidx >= n_seq) return fail(ctx, PWA_E_INVALID, "pair index out of range");
+                if (stamp[sidx] != chunk) total += align_up(seq_off[sidx + 1] - seq_off[sidx] + 1, 16);
+                stamp[sidx] = chunk;
+            }
+        if (total > (96ull << 20)) limit = std::min<uint64_t>(limit, std::max<uint64_t>(32ull << 20, total / 6 + (1ull << 20)));
+    }
+    struct InFlight {
+        pwa_batch* b = nullptr;
+        uint64_t k0 = 0;
+    } prev;
+    auto collect = [&](InFlight& f) -> int {   // wait for the run's own event, copy its results out, recycle its buffers
+        if (!f.b) return PWA_OK;
+        const int rc = pwa_batch_fetch(f.b, score_out + f.k0, end_i_out ? end_i_out + f.k0 : nullptr, end_j_out ? end_j_out + f.k0 : nullptr);
+        pwa_batch_destroy(f.b);
+        f.b = nullptr;
+        return rc;
+    };
+    uint64_t k0 = 0, n_runs = 0;
+    int rc = PWA_OK;
+    const auto t_begin = std::chrono::steady_clock::now();
+    while (k0 < n_pairs && rc == PWA_OK) {
+        ++chunk;
+        ++n_runs;
         uint64_t k1 = k0, bytes = 512;
         for (; k1 < n_pairs; ++k1) {
             uint64_t add = 0;
             for (const uint32_t sidx : {pair_a[k1], pair_b[k1]}) {
-                if (sidx >= n_seq) return fail(ctx, PWA_E_INVALID, "pair index out of range");
+                if (sidx >= n_seq) {
+                    (void)collect(prev);
+                    return fail(ctx, PWA_E_INVALID, "pair index out of range");
+                }
                 if (stamp[sidx] != chunk) add += align_up(seq_off[sidx + 1] - seq_off[sidx] + 1, 16);
             }
             if (pair_a[k1] == pair_b[k1] && stamp[pair_a[k1]] != chunk) add /= 2;
@@ -1755,21 +1832,29 @@ static int scores_in_arena_chunks(pwa_ctx* ctx, const uint64_t* seq_off, uint32_
             stamp[pair_a[k1]] = stamp[pair_b[k1]] = chunk;
         }
         pwa_batch* b = nullptr;
-        int rc = create(pair_a + k0, pair_b + k0, k1 - k0, &b);
+        rc = create(pair_a + k0, pair_b + k0, k1 - k0, &b);   // host work + uploads: overlaps the kernels of the previous run
         // the arena estimate above is not the only 32-bit limit inside a batch object (per-lane text rows of the LANES form, slot
         // arrays): a run that is refused for its size is halved until it fits -- pairs are independent (hw2.cpp:328-338)
         while (rc == PWA_E_CAPACITY && k1 - k0 > 1) {
             k1 = k0 + (k1 - k0) / 2;
             rc = create(pair_a + k0, pair_b + k0, k1 - k0, &b);
         }
-        if (rc != PWA_OK) return rc;
-        rc = pwa_batch_run(b, nullptr);
-        if (rc == PWA_OK) rc = pwa_batch_fetch(b, score_out + k0, end_i_out ? end_i_out + k0 : nullptr, end_j_out ? end_j_out + k0 : nullptr);
-        pwa_batch_destroy(b);
-        if (rc != PWA_OK) return rc;
+        if (rc == PWA_OK) rc = pwa_batch_run(b, nullptr);      // queued behind the previous run on the context's stream
+        const int rc_prev = collect(prev);                      // ... whose results are copied out meanwhile
+        if (rc == PWA_OK) {
+            prev.b = b;
+            prev.k0 = k0;
+            rc = rc_prev;
+        } else if (b) {
+            pwa_batch_destroy(b);
+        }
         k0 = k1;
-    } while (k0 < n_pairs);
-    return PWA_OK;
+    }
+    const int rc_last = collect(prev);
+    if (ctx->knobs.debug)
+        std::fprintf(stderr, "[pwa] scores pass: %llu pairs in %llu pipelined run(s) of <= %llu MB of sequences, %.3f ms in all\n", (unsigned long long)n_pairs,
+                     (unsigned long long)n_runs, (unsigned long long)(limit >> 20), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    return rc != PWA_OK ? rc : rc_last;
 } catch (const std::bad_alloc&) {
     return fail(ctx, PWA_E_NOMEM, "host allocation failed");
 }

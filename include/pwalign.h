@@ -21,6 +21,27 @@
  *     prints across the ABI; pwa_last_error() gives the text of the last failure on a context;
  *   - a context is bound to ONE GPU and is not thread-safe: one context per host thread.
  *   - there is NO CPU fallback: without a usable GPU pwa_ctx_create fails with PWA_E_NODEVICE.
+ *
+ * Engines (chosen by the library, never by the caller; all exact, so the choice changes no result):
+ *   strip engine       scores only: lane = pair, register strips (batch_scores.hip.h);
+ *   stripe engine      one wave per 64 RL rows of a pair, anti-diagonal front, stripes pipelined (pair_fill.hip.h): traceback fills
+ *                      of long patterns, scores with end cells, and -- by estimated cost -- the scores of pairs that would leave the
+ *                      strip engine's waves under-filled (a few long pairs);
+ *   mini-stripe engine 16 lanes per pair, four pairs per wave (mini_fill.hip.h): traceback fills of patterns of up to 256 rows.
+ *   pwa_align_batch / pwa_overlaps pick the band geometry pair by pair; pwa_scores / pwa_batch_create split a list between the strip
+ *   and the stripe engine.
+ *
+ * Environment switches (tests and diagnostics only).  They are read ONCE, by pwa_ctx_create, into the context; no other entry point
+ * consults the environment, so a process that wants another setting creates another context.  (pwa_fasta_read, which has no context,
+ * reads PWA_FASTA_MIN_CHUNK -- bytes per parser chunk -- on every call.)
+ *   PWA_DEBUG, PWA_PROBE          host-side phase times / nop-kernel probes on stderr
+ *   PWA_SCORES_ROUTE=0|1          scores passes: 0 every pair on the strip engine, 1 every pair on the stripe engine (default: by cost)
+ *   PWA_TB_ENGINE=0               traceback fills: stripe engine only (default: mini-stripe engine for patterns of <= 256 rows)
+ *   PWA_NO_PIPELINE               one-shot score calls are not cut into pipelined runs (only at 4 GiB of sequences)
+ *   PWA_ARENA_LIMIT, PWA_LANE_ROWS_LIMIT   bytes per run of the one-shot calls / per-lane text rows per batch (force the multi-run paths)
+ *   PWA_NO_PAIR_TABLE, PWA_NO_KEYED_TB, PWA_NO_GAP_SHIFT, PWA_NO_TILED_OPS, PWA_NO_PACKED_DIST, PWA_PAIRED, PWA_FORCE_LANES,
+ *   PWA_FORCE_R, PWA_FORCE_MODE, PWA_FORCE_RL, PWA_FORCE_W, PWA_WG_PER_CU, PWA_NO_LDS_PAD, PWA_STAMPS, PWA_TRACE_STRIPE
+ *                                 select one of several equivalent kernel forms / geometries, or record time stamps
  */
 #ifndef PWALIGN_H
 #define PWALIGN_H
@@ -72,7 +93,8 @@ int pwa_ctx_set_score_band(pwa_ctx *ctx, int on);
  *                       NW (n, m); SW the FIRST maximum in row-major order, (0,0) if all zero.
  * Pair lists of any size: a batch object addresses its sequence arena with 32-bit offsets (4 GiB of distinct sequences),
  * so this call (like pwa_distances and pwa_scores_affine) cuts the list into runs of consecutive pairs whose sequences
- * fit one arena and processes them one after the other.  Remaining limits: a sequence < 2^31 - 64 symbols; pattern +
+ * fit one arena -- and lists of more than ~100 MB of sequences into about six runs in any case -- and PIPELINES them: run k + 1 is
+ * scheduled, coded and uploaded while the kernels of run k execute (readFasta's output overlaps its own consumption).  Remaining limits: a sequence < 2^31 - 64 symbols; pattern +
  * reference of ONE pair < 4 GiB; < 2^32 - 1 pairs per call.
  */
 int pwa_scores(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const uint8_t *seq_bytes,
@@ -201,7 +223,9 @@ int pwa_align_last_stats(const pwa_ctx *ctx, float *fill_ms, float *traceback_ms
  * ops_off so that pair k has room for n_k + m_k bytes.  When the regions follow one another without a gap
  * (ops_off[k + 1] == ops_off[k] + n_k + m_k) the device op buffer mirrors the caller's and every chunk of pairs comes
  * back with one copy straight into `ops`; any other layout works through a staging copy.  No sequence-arena limit here
- * (64-bit device pointers); the traceback bands are processed in chunks that fit the free HBM.
+ * (64-bit device pointers); the traceback bands are processed in ranges of consecutive pairs that fit the free HBM, and inside a
+ * range every pair runs with the band geometry its own pattern length asks for.  Bytes of a pair's region beyond n_ops[k] are
+ * undefined after the call.
  */
 int pwa_align_batch(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const uint8_t *seq_bytes,
                     const uint64_t *seq_off, uint32_t n_seq, const uint32_t *pair_a, const uint32_t *pair_b,

@@ -50,6 +50,23 @@ def test_self_launch_two_ranks_gloo(workload):
         assert line["dist"]["gathered_score_sum"] == want
 
 
+@pytest.mark.parametrize("workload,mode", [("g", "nw"), ("gb", "sw")])
+def test_full_alignment_batches_shard_over_ranks(workload, mode):
+    """r03: --workload g / gb honour --gpus N: the list of N x 4096 pairs is dealt in contiguous blocks (rank r: block r), every rank
+    aligns its block in full, ONE all-gather per step carries the per-pair scores and op counts of all blocks to every rank."""
+    pr = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload, "--small", "--rehearse-cpu"])
+    assert pr.returncode == 0, pr.stderr.decode()[-2000:]
+    lines = [l for l in pr.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout.decode()
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "invalid" in line
+    assert line["dist"]["world_size"] == 2 and line["dist"]["backend"] == "gloo" and line["dist"]["gathered_identical_on_all_ranks"] is True
+    txts = [O.gen(1, 1, t, 200) for t in range(4)]
+    want = sum(O.score(mode, O.gen(1, 0, r * 8 + p, 40), txts[p % 4], 1, -1, -1)[0] for r in range(2) for p in range(8))
+    assert line["dist"]["gathered_score_sum"] == want
+    assert line["verified_vs_cpu"]["bit_exact"] is True
+
+
 def test_gpus_must_match_world_size():
     pr = _run(["--gpus", "2", "--small", "--rehearse-cpu"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert pr.returncode != 0 and b"WORLD_SIZE=1" in pr.stderr

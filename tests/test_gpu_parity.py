@@ -874,6 +874,27 @@ def test_one_shot_calls_cut_oversized_pair_lists_into_arena_chunks(ctx):
         assert c.scores_affine_oneshot(seqs, pa, pb, 5, -4, -16, -4) == whole_a == [O.affine_score(seqs[a], seqs[b], 5, -4, -16, -4) for a, b in zip(pa, pb)]
 
 
+def test_one_shot_scores_are_pipelined_over_runs(ctx):
+    """r03: pwa_scores on a list whose sequences exceed ~100 MB is cut into about six runs that are prepared (coded,
+    uploaded) while the previous run computes; results must equal the unpipelined call (PWA_NO_PIPELINE) pair for pair, and the oracle
+    on a sample.  Index-paired (the reference's own loop, hw2.cpp:328-338) and with shared texts."""
+    import numpy as np
+    import bench
+    n = 9000
+    pats = [bench.gen(50, 0, i, 100 + i % 60) for i in range(n)]
+    txts = [bench.gen(50, 1, i, 11000 + 37 * (i % 50)) for i in range(n)]   # ~100 MB of texts
+    seqs = pats + txts
+    pa = list(range(n)) + [5, 6, 7]
+    pb = [n + k for k in range(n)] + [n + 1, n + 1, n + 1]
+    for mode in ("sw", "nw"):
+        got = ctx.scores(mode, seqs, pa, pb, 1, -1, -1)
+        with switched_context(PWA_NO_PIPELINE="1") as c:
+            assert c.scores(mode, seqs, pa, pb, 1, -1, -1) == got, mode
+        rs = np.random.RandomState(5)
+        for k in list(rs.choice(len(pa), 40, replace=False)) + [0, n - 1, n, n + 2]:
+            assert got[k] == O.score(mode, seqs[pa[k]], seqs[pb[k]], 1, -1, -1)[0], (mode, k)
+
+
 @pytest.mark.parametrize("engine,n_class", [("stripes", (1, 63, 64)), ("stripes", (65, 127, 128)), ("stripes", (129, 200, 256)),
                                             ("stripes", (257, 300, 511, 512, 513)), ("stripes", (700, 1025, 1100, 1537)),
                                             ("mini", (1, 15, 16, 17, 63, 64)), ("mini", (65, 95, 96, 97, 127, 128)),
