@@ -163,8 +163,12 @@ constexpr int strip_waves_per_simd(int R, int MODE) {
 // columns past a lane's own text are fed the symbol that matches nothing: local scores can then only decay, so
 // the lane's maximum is already final (the same argument that pads short patterns).  ~+3 % VALU per cell
 // against the shared-text form, against up to 64x fewer idle lanes on index-paired lists.
+// Launch geometry: workgroups of ONE or of FOUR waves (the host's choice); every wave pulls its own tasks and owns its own hand-off region.
+// Four-wave workgroups that each ask for a share of the CU's LDS are how the host gets a BALANCED placement -- the same number of
+// waves on every SIMD -- whatever kernel ran before ([gpu, r03] tools/probes/simd_place2.hip: single-wave workgroups launched after
+// another kernel double up on some SIMDs and leave others empty).
 template <int R, int MODE, int SCORE, bool MULTI, bool LANES = false>
-__global__ __launch_bounds__(64, strip_waves_per_simd(R, MODE)) void batch_scores_kernel(const BatchParams P) {
+__global__ __launch_bounds__(256, strip_waves_per_simd(R, MODE)) void batch_scores_kernel(const BatchParams P) {
     // Global alignment, gap-shifted form, coded alphabets of <= 4 symbols: the texts of a task are RIGHT-aligned.  The
     // host stores every lane's text as a row of M = 4*ceil(max m / 4) codes, front-padded with code 4, which the
     // table scores like a gap (H-space g, here -g): with g <= 0 such a column reproduces column 0 exactly
@@ -172,8 +176,8 @@ __global__ __launch_bounds__(64, strip_waves_per_simd(R, MODE)) void batch_score
     // block, and H[n][m] = G'[n][M] + g(n + M).  Only row 0 differs per lane: H[0][j] = g * max(j - p, 0).
     static_assert(!LANES || MODE == BM_SWS || MODE == BM_SW || MODE == BM_NWG, "per-lane texts: SW forms and gap-shifted NW");
     constexpr int Q = R / 4;
-    const int lane = threadIdx.x;
-    int32_t* const hand = P.hand + (size_t)blockIdx.x * P.hand_stride;
+    const int lane = threadIdx.x & 63;
+    int32_t* const hand = P.hand + ((size_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * P.hand_stride;
 
     for (;;) {
         uint32_t tid = 0;

@@ -71,7 +71,9 @@ struct Knobs {
     bool no_keyed_tb = false;                   // PWA_NO_KEYED_TB: traceback fills in the plain int32 form
     bool no_gap_shift = false;                  // PWA_NO_GAP_SHIFT: global traceback fills in H, not G = H - gap (i + j)
     bool no_tiled_ops = false;                  // PWA_NO_TILED_OPS: op lists through the staging copy
-    bool no_pipeline = false;                   // PWA_NO_PIPELINE: one-shot score calls are not cut into pipelined runs (only at 4 GiB of sequences)
+    bool strip_wg1 = false;                     // PWA_STRIP_WG1: strip kernels as single-wave workgroups (r02 form; A/B of the placement effect)
+    bool no_pipeline = false;                   // PWA_NO_PIPELINE: the runs of a one-shot score call are processed strictly one after the other
+    int pipe_runs = 0;                          // PWA_PIPE_RUNS=N: cut a list that fits one arena into N pipelined runs (experiment; measured slower)
     int scores_route = -1;                      // PWA_SCORES_ROUTE: 0 = every pair on the strip engine, 1 = every pair on the stripe
                                                 // engine, unset = by estimated cost (batch_create_impl)
     int tb_engine = -1;                         // PWA_TB_ENGINE: 0 = stripe engine only, 1 = mini-stripe engine wherever it applies,
@@ -99,6 +101,8 @@ struct Knobs {
         no_gap_shift = flag("PWA_NO_GAP_SHIFT");
         no_tiled_ops = flag("PWA_NO_TILED_OPS");
         no_pipeline = flag("PWA_NO_PIPELINE");
+        pipe_runs = num("PWA_PIPE_RUNS", 0);
+        strip_wg1 = flag("PWA_STRIP_WG1");
         scores_route = num("PWA_SCORES_ROUTE", -1);
         tb_engine = num("PWA_TB_ENGINE", -1);
     }
@@ -1285,6 +1289,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             const uint64_t per_wg = (half + second) * sizeof(int32_t);
             const uint64_t fit = std::max<uint64_t>(1, (uint64_t)(free_b * 0.6) / per_wg);
             b->grid = (uint32_t)std::min<uint64_t>(b->grid, fit);
+            b->grid = (b->grid + 3u) & ~3u;   // whole four-wave workgroups (pwa_batch_run): every wave has a hand-off region of its own
         }
         {
             const size_t hand_bytes = (size_t)b->grid * (half + second) * sizeof(int32_t);
@@ -1638,9 +1643,22 @@ int pwa_batch_run(pwa_batch* b, void* stream_v) {
                 ap.neg = b->aff_neg;
                 hipLaunchKernelGGL(b->kern->afn, dim3(b->grid), dim3(64), 0, st, ap);
             } else {
-                if (b->lanes) hipLaunchKernelGGL(b->single_strip ? b->kern->fn_lanes_single : b->kern->fn_lanes, dim3(b->grid), dim3(64), 0, st, b->bp);
-                else if (b->paired) hipLaunchKernelGGL(b->kern->fn_pair, dim3(b->grid), dim3(128), 0, st, b->bp);
-                else hipLaunchKernelGGL(b->single_strip ? b->kern->fn_single : b->kern->fn, dim3(b->grid), dim3(64), 0, st, b->bp);
+                if (b->paired) {
+                    hipLaunchKernelGGL(b->kern->fn_pair, dim3(b->grid), dim3(128), 0, st, b->bp);
+                } else {
+                    // b->grid waves as workgroups of four, with an LDS request that admits exactly their share per CU: a balanced
+                    // placement whatever ran before (batch_scores.hip.h); PWA_STRIP_WG1: single-wave workgroups (A/B)
+                    const batch_kernel_t fn = b->lanes ? (b->single_strip ? b->kern->fn_lanes_single : b->kern->fn_lanes) : (b->single_strip ? b->kern->fn_single : b->kern->fn);
+                    if (ctx->knobs.strip_wg1) {
+                        hipLaunchKernelGGL(fn, dim3(b->grid), dim3(64), 0, st, b->bp);
+                    } else {
+                        const uint32_t n_wg = (b->grid + 3) / 4, per_cu = (n_wg + (uint32_t)ctx->num_cu - 1) / (uint32_t)ctx->num_cu;
+                        static const uint32_t kPadKiB[6] = {0, 96, 64, 48, 36, 30};
+                        const size_t pad_lds = per_cu <= 5 ? (size_t)kPadKiB[per_cu] * 1024 : 0;
+                        HIPC(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds));
+                        hipLaunchKernelGGL(fn, dim3(n_wg), dim3(256), pad_lds, st, b->bp);
+                    }
+                }
             }
             HIPC(ctx, hipGetLastError());
         }
@@ -1778,9 +1796,12 @@ static uint64_t arena_limit(const pwa_ctx* ctx) {
 }
 // r03 (overlap H2D with compute): the runs are PIPELINED -- while the kernels of run k execute, run k + 1 is validated,
 // scheduled, coded and uploaded (copy stream, page-locked pieces) and its kernels are queued behind; the host then collects run k.
-// And a list whose sequences exceed ~100 MB is cut into runs on purpose (about six), although one arena would hold it, so that the
-// first kernels start when a sixth of the input is on the device instead of all of it.  Destroyed runs hand their device buffers
-// to the context's free list (no hipFree: it would wait for the run in flight).
+// Destroyed runs hand their device buffers to the context's free list (no hipFree: it would wait for the run in flight).
+// Cutting a list that FITS one arena into several runs, so that the first kernels start before all of the input is on the device, was
+// built and measured (PWA_PIPE_RUNS=6) and is not the default: [gpu] hw2_amd -l on 262 144 pairs 150 x 2000 (569 MB): scores pass 87 ms in
+// one run, 116 ms in six -- the kernels of that input take 9 ms, the rest is host work per run (alphabet scans, sorts, uploads with their
+// synchronisations), which six runs pay six times; 4.5 GB (two arenas): 348 ms in two pipelined runs, 477 ms in six
+// (profiles/r03_cli_scale.txt).
 template <class Create>
 static int scores_in_arena_chunks(pwa_ctx* ctx, const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,
                                   uint64_t n_pairs, int32_t* score_out, uint32_t* end_i_out, uint32_t* end_j_out, Create&& create) try {
@@ -1788,7 +1809,7 @@ static int scores_in_arena_chunks(pwa_ctx* ctx, const uint64_t* seq_off, uint32_
     uint64_t limit = arena_limit(ctx);
     std::vector<uint64_t> stamp(n_seq, 0);
     uint64_t chunk = 0;
-    if (!ctx->knobs.arena_limit && !ctx->knobs.no_pipeline) {   // arena bytes of the whole list: is it worth cutting for the pipeline?
+    if (!ctx->knobs.arena_limit && ctx->knobs.pipe_runs > 1) {   // experiment: cut a list that fits one arena into PWA_PIPE_RUNS runs
         ++chunk;
         uint64_t total = 512;
         for (uint64_t k = 0; k < n_pairs; ++k)
@@ -1797,7 +1818,7 @@ static int scores_in_arena_chunks(pwa_ctx* ctx, const uint64_t* seq_off, uint32_
                 if (stamp[sidx] != chunk) total += align_up(seq_off[sidx + 1] - seq_off[sidx] + 1, 16);
                 stamp[sidx] = chunk;
             }
-        if (total > (96ull << 20)) limit = std::min<uint64_t>(limit, std::max<uint64_t>(32ull << 20, total / 6 + (1ull << 20)));
+        limit = std::min<uint64_t>(limit, std::max<uint64_t>(1ull << 20, total / (uint64_t)ctx->knobs.pipe_runs + (1ull << 20)));
     }
     struct InFlight {
         pwa_batch* b = nullptr;
@@ -1845,6 +1866,7 @@ static int scores_in_arena_chunks(pwa_ctx* ctx, const uint64_t* seq_off, uint32_
             prev.b = b;
             prev.k0 = k0;
             rc = rc_prev;
+            if (ctx->knobs.no_pipeline && rc == PWA_OK) rc = collect(prev);   // A/B: every run is collected before the next one is prepared
         } else if (b) {
             pwa_batch_destroy(b);
         }

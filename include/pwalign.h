@@ -37,7 +37,7 @@
  *   PWA_DEBUG, PWA_PROBE          host-side phase times / nop-kernel probes on stderr
  *   PWA_SCORES_ROUTE=0|1          scores passes: 0 every pair on the strip engine, 1 every pair on the stripe engine (default: by cost)
  *   PWA_TB_ENGINE=0               traceback fills: stripe engine only (default: mini-stripe engine for patterns of <= 256 rows)
- *   PWA_NO_PIPELINE               one-shot score calls are not cut into pipelined runs (only at 4 GiB of sequences)
+ *   PWA_NO_PIPELINE, PWA_PIPE_RUNS=N  one-shot score calls: runs strictly one after the other / a list that fits one arena cut into N runs
  *   PWA_ARENA_LIMIT, PWA_LANE_ROWS_LIMIT   bytes per run of the one-shot calls / per-lane text rows per batch (force the multi-run paths)
  *   PWA_NO_PAIR_TABLE, PWA_NO_KEYED_TB, PWA_NO_GAP_SHIFT, PWA_NO_TILED_OPS, PWA_NO_PACKED_DIST, PWA_PAIRED, PWA_FORCE_LANES,
  *   PWA_FORCE_R, PWA_FORCE_MODE, PWA_FORCE_RL, PWA_FORCE_W, PWA_WG_PER_CU, PWA_NO_LDS_PAD, PWA_STAMPS, PWA_TRACE_STRIPE
@@ -93,8 +93,7 @@ int pwa_ctx_set_score_band(pwa_ctx *ctx, int on);
  *                       NW (n, m); SW the FIRST maximum in row-major order, (0,0) if all zero.
  * Pair lists of any size: a batch object addresses its sequence arena with 32-bit offsets (4 GiB of distinct sequences),
  * so this call (like pwa_distances and pwa_scores_affine) cuts the list into runs of consecutive pairs whose sequences
- * fit one arena -- and lists of more than ~100 MB of sequences into about six runs in any case -- and PIPELINES them: run k + 1 is
- * scheduled, coded and uploaded while the kernels of run k execute (readFasta's output overlaps its own consumption).  Remaining limits: a sequence < 2^31 - 64 symbols; pattern +
+ * fit one arena and PIPELINES them: run k + 1 is scheduled, coded and uploaded while the kernels of run k execute.  Remaining limits: a sequence < 2^31 - 64 symbols; pattern +
  * reference of ONE pair < 4 GiB; < 2^32 - 1 pairs per call.
  */
 int pwa_scores(pwa_ctx *ctx, int mode, int match, int mismatch, int gap, const uint8_t *seq_bytes,

@@ -125,3 +125,11 @@ def test_cli_argument_errors_match_reference(tmp_path):
         assert got == want, case["args"]
         ran += 1
     assert ran >= 5
+
+
+def test_pack_sequences_takes_a_tuple_of_three_sequences_as_sequences(pkg):
+    """a 3-tuple of byte strings is a list of three sequences, not an already packed (blob, offsets, list) triple"""
+    blob, off, seqs = pkg.pack_sequences((b"ACGT", b"ACG", b"AC"))
+    assert blob == b"ACGTACGAC" and list(off) == [0, 4, 7, 9] and seqs == [b"ACGT", b"ACG", b"AC"]
+    again = pkg.pack_sequences((blob, off, seqs))
+    assert again[0] is blob and again[1] is off

@@ -874,10 +874,28 @@ def test_one_shot_calls_cut_oversized_pair_lists_into_arena_chunks(ctx):
         assert c.scores_affine_oneshot(seqs, pa, pb, 5, -4, -16, -4) == whole_a == [O.affine_score(seqs[a], seqs[b], 5, -4, -16, -4) for a, b in zip(pa, pb)]
 
 
+def test_one_shot_calls_halve_runs_that_exceed_a_batch_object_limit():
+    """the arena estimate is not the only 32-bit limit inside a batch object -- the right-aligned per-lane text rows of the
+    global LANES form have their own (here lowered to 64 KiB through PWA_LANE_ROWS_LIMIT).  pwa_batch_create refuses such a list
+    (PWA_E_CAPACITY); the one-shot call halves the run until it fits and must still return every score."""
+    rng = random.Random(962)
+    n = 900
+    pats = [bytes(rng.choice(b"ACGT") for _ in range(rng.randint(20, 120))) for _ in range(n)]
+    txts = [bytes(rng.choice(b"ACGT") for _ in range(rng.randint(100, 500))) for _ in range(n)]
+    seqs = pats + txts
+    pa, pb = list(range(n)), [n + k for k in range(n)]
+    want = [O.score("nw", seqs[a], seqs[b], 1, -1, -1)[0] for a, b in zip(pa, pb)]
+    with switched_context(PWA_LANE_ROWS_LIMIT="65536", PWA_SCORES_ROUTE="0") as c:
+        with pytest.raises(Exception, match="capacity"):
+            c.batch("nw", seqs, pa, pb, 1, -1, -1)
+        assert c.scores("nw", seqs, pa, pb, 1, -1, -1) == want
+
+
 def test_one_shot_scores_are_pipelined_over_runs(ctx):
-    """r03: pwa_scores on a list whose sequences exceed ~100 MB is cut into about six runs that are prepared (coded,
-    uploaded) while the previous run computes; results must equal the unpipelined call (PWA_NO_PIPELINE) pair for pair, and the oracle
-    on a sample.  Index-paired (the reference's own loop, hw2.cpp:328-338) and with shared texts."""
+    """r03: the runs of a one-shot score call are prepared (coded, uploaded) while the previous run computes.  A ~100 MB
+    list cut into six runs (PWA_PIPE_RUNS=6; by default only lists beyond one 4 GiB arena are cut) must give the results of the single
+    run and of the strictly serial form (PWA_NO_PIPELINE) pair for pair, and the oracle's on a sample.  Index-paired (the reference's
+    own loop, hw2.cpp:328-338) plus pairs that share a text."""
     import numpy as np
     import bench
     n = 9000
@@ -888,7 +906,9 @@ def test_one_shot_scores_are_pipelined_over_runs(ctx):
     pb = [n + k for k in range(n)] + [n + 1, n + 1, n + 1]
     for mode in ("sw", "nw"):
         got = ctx.scores(mode, seqs, pa, pb, 1, -1, -1)
-        with switched_context(PWA_NO_PIPELINE="1") as c:
+        with switched_context(PWA_PIPE_RUNS="6") as c:
+            assert c.scores(mode, seqs, pa, pb, 1, -1, -1) == got, mode
+        with switched_context(PWA_PIPE_RUNS="6", PWA_NO_PIPELINE="1") as c:
             assert c.scores(mode, seqs, pa, pb, 1, -1, -1) == got, mode
         rs = np.random.RandomState(5)
         for k in list(rs.choice(len(pa), 40, replace=False)) + [0, n - 1, n, n + 2]:
