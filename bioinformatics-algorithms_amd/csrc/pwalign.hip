@@ -2281,6 +2281,8 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         }
         mark("scatter to caller buffers");
     }
+    if (dbg) std::fprintf(stderr, "[pwa] %s: %llu pairs in %zu range(s): fills %.3f ms, walks %.3f ms (device), %.2f GB of band written\n", want_ops ? "align_batch" : "overlaps",
+                          (unsigned long long)n_pairs, ranges.size(), ctx->fill_ms, ctx->tb_ms, (double)ctx->band_bytes / 1e9);
     return PWA_OK;
 } catch (const std::bad_alloc&) {
     return fail(ctx, PWA_E_NOMEM, "host allocation failed");

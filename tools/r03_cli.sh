@@ -18,6 +18,7 @@ run() {  # name flags...
       done
     done
     PWA_DEBUG=1 $EXE -l -p $D/p$name.fasta -t $D/t$name.fasta -o $D/dbg.txt -s 1 -1 -1 2>&1 | grep "scores pass" | sed "s/^/input $name  -l  $mode  /"
+    if [ $mode = default ]; then PWA_DEBUG=1 $EXE -g -p $D/p$name.fasta -t $D/t$name.fasta -o $D/dbg.txt -s 1 -1 -1 2>&1 | grep "overlaps:" | sed "s/^/input $name  -g  /"; fi
   done
   unset PWA_NO_PIPELINE PWA_PIPE_RUNS
   sha256sum $D/l$name.default.txt $D/l$name.six-runs.txt $D/l$name.serial.txt $D/g$name.default.txt | awk '{print substr($1,1,16), $2}'
