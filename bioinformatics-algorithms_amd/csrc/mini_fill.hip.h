@@ -50,7 +50,7 @@ __device__ __forceinline__ int mini_pick_lane0(int dst, int v) {
 
 // 16 steps of four pairs.  GUARD: some lane of the wave is outside its matrix at some step of the chunk (the first 15
 // steps, and from the shortest text's last column on): that lane's state is frozen (pair_fill.hip.h, keyed_chunk).
-template <int RL, bool LOCAL, bool SBAND, bool GUARD, bool GAP0>
+template <int RL, bool LOCAL, bool SBAND, bool GUARD, bool GAP0, bool BAND = true>
 __device__ __forceinline__ void mini_chunk(const int t0, const int k, const int m, const uint32_t (&pk)[(RL + 3) / 4], int (&hl)[RL], int& diag0,
                                            int& bottom, int& tch, const int tcv, const int top0, const int top_inc, int (&bs)[RL], int (&bj)[RL],
                                            const uint32_t tab_lo, const uint32_t tab_hi, const int cl, g_u8* const tba, g_u8* const tbb,
@@ -105,7 +105,7 @@ __device__ __forceinline__ void mini_chunk(const int t0, const int k, const int 
 #ifdef PWA_MINI_NOSTORE   // timing-only experiment builds (results are wrong): what the fill costs without its band stores
         if (t0 == 0x7ffffff0)
 #endif
-        {
+        if constexpr (BAND) {
         if constexpr (Geo::PA == 4) PWA_BAND_STORE((g_u32*)(tba + q * Geo::SR), codes[0]);
         if constexpr (Geo::PA == 8) PWA_BAND_STORE((PWA_GLOBAL mu32x2*)(tba + q * Geo::SR), (mu32x2{codes[0], codes[1]}));
         if constexpr (Geo::PA == 16) PWA_BAND_STORE((PWA_GLOBAL mu32x4*)(tba + q * Geo::SR), (mu32x4{codes[0], codes[1], codes[2], codes[3]}));
@@ -125,9 +125,12 @@ __device__ __forceinline__ void mini_chunk(const int t0, const int k, const int 
 // after an idle GPU or after itself, but 2.4 ms whenever another kernel (the walk, a copy kernel, any large grid) had run before it:
 // the dispatcher then starts somewhere else in its round-robin and doubles waves up on some SIMDs while others stay empty -- and a
 // wave that runs one 1.3 ms task cannot be rebalanced.
+// BAND = false: the same fill without any band -- scores (and, local, the first-maximum end cell) of short-pattern pairs that a scores
+// pass routes away from the strip engine (pwalign.hip, batch_create_impl): four pairs per wave instead of one 256-row stripe per pair.
 constexpr int kMiniWaves = 4;
-template <int RL, bool LOCAL, bool SBAND, bool GAP0>
+template <int RL, bool LOCAL, bool SBAND, bool GAP0, bool BAND = true>
 __global__ __launch_bounds__(64 * kMiniWaves) void mini_fill_kernel(const PairParams G) {
+    static_assert(BAND || !SBAND, "no score band without the code band");
     typedef BandGeo<16, RL> Geo;
     constexpr int NQ = (RL + 3) / 4;
     constexpr int PU = TbCode<LOCAL>::UP, PL = TbCode<LOCAL>::LEFT;
@@ -213,11 +216,11 @@ __global__ __launch_bounds__(64 * kMiniWaves) void mini_fill_kernel(const PairPa
             g_i32* const sbs = SBAND ? sband + (size_t)t0 * Geo::SR + k * RL : nullptr;
             const bool interior = t0 >= 15 && t0 + 16 <= mmin;   // every lane of every pair inside its matrix
             if (interior)
-                mini_chunk<RL, LOCAL, SBAND, false, GAP0>(t0, k, m, pk, hl, diag0, bottom, tch, tcv, top0, top_inc, bs, bj, tab_lo, tab_hi, cl, tbs + offa,
-                                                          tbs + offb, sbs);
+                mini_chunk<RL, LOCAL, SBAND, false, GAP0, BAND>(t0, k, m, pk, hl, diag0, bottom, tch, tcv, top0, top_inc, bs, bj, tab_lo, tab_hi, cl,
+                                                                tbs + offa, tbs + offb, sbs);
             else
-                mini_chunk<RL, LOCAL, SBAND, true, GAP0>(t0, k, m, pk, hl, diag0, bottom, tch, tcv, top0, top_inc, bs, bj, tab_lo, tab_hi, cl, tbs + offa,
-                                                         tbs + offb, sbs);
+                mini_chunk<RL, LOCAL, SBAND, true, GAP0, BAND>(t0, k, m, pk, hl, diag0, bottom, tch, tcv, top0, top_inc, bs, bj, tab_lo, tab_hi, cl,
+                                                               tbs + offa, tbs + offb, sbs);
         }
         PWA_GLOBAL PairResult* const res = (PWA_GLOBAL PairResult*)P->res;
         if (!LOCAL) {

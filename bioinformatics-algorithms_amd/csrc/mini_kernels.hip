@@ -9,7 +9,9 @@ static pair_kernel_t mini_fill_pick(bool local, bool sband, bool gap0) {
     if (local) return sband ? mini_fill_kernel<RL, true, true, false> : mini_fill_kernel<RL, true, false, false>;
     return sband ? mini_fill_kernel<RL, false, true, false> : mini_fill_kernel<RL, false, false, false>;
 }
-pair_kernel_t mini_fill_kernel_for(int rl, bool local, bool sband, bool gap0) {
+pair_kernel_t mini_scores_kernel_for(int rl, bool local, bool gap0);   // mini_kernels_noband.hip
+pair_kernel_t mini_fill_kernel_for(int rl, bool local, bool sband, bool gap0, bool band) {
+    if (!band) return sband ? nullptr : mini_scores_kernel_for(rl, local, gap0);
     switch (rl) {
         case 4: return mini_fill_pick<4>(local, sband, gap0);
         case 6: return mini_fill_pick<6>(local, sband, gap0);

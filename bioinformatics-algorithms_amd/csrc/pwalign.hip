@@ -136,6 +136,8 @@ struct pwa_ctx {
     void* pool[POOL_N] = {};
     size_t pool_bytes[POOL_N] = {};
     // page-locked staging of everything the library itself uploads or reads back (see PinnedBuf)
+    hipStream_t aux_stream = nullptr;                  // pwa_batch_run: the mini-stripe launches of a split batch run next to its stripe launch
+    hipEvent_t aux_ev[2] = {nullptr, nullptr};         // fork / join of that
     hipStream_t copy_stream = nullptr;                 // uploads that overlap host work (build_arena)
     hipEvent_t copy_ev[2] = {nullptr, nullptr};
     // Device buffers of destroyed batch objects, kept for the next one (DevBuf below): a steady stream of batches -- the runs of a
@@ -543,9 +545,9 @@ struct PairLaunch {
     int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, int walk, hipEvent_t after_fill, bool sband = false) {
         HIPC(ctx, hipMemsetAsync(p_queue, 0, 16, st));
         if (mini) {
-            const pair_kernel_t fill = mini_fill_kernel_for(geom.rl, local, sband, gap0 && !sband && !local);
-            const pair_kernel_t walk_fn = mini_traceback_kernel_for(geom.rl, local, walk);
-            if (!fill || !walk_fn || !tb || !perm || !keyed) return fail(ctx, PWA_E_INVALID, "internal: no mini-stripe kernel for this form");
+            const pair_kernel_t fill = mini_fill_kernel_for(geom.rl, local, sband, gap0 && !sband && !local, tb);   // tb = false: no band at all
+            const pair_kernel_t walk_fn = mini_traceback_kernel_for(geom.rl, local, tb ? walk : (int)WALK_NONE);
+            if (!fill || !walk_fn || !perm || !keyed) return fail(ctx, PWA_E_INVALID, "internal: no mini-stripe kernel for this form");
             // Workgroups of four waves (one task each per round); `per_cu` of them per CU, enforced through the dynamic LDS request, so
             // that no CU gets more than its share whatever ran before (mini_fill.hip.h): with ceil(tasks / 4) workgroups for 256 CUs,
             // per_cu = ceil(workgroups / CUs), at most 2; longer task lists run in rounds ([gpu] pairs 150 x 10k: 8192 of them at two
@@ -634,6 +636,7 @@ struct pwa_batch {
     DevBuf arena, tasks, slot_poff, slot_plen, slot_out, slot_toff, slot_tlen, lane_text, hand, queue, scores;
     // engine 2: wavefront kernels without traceback band (exact end cells, any scoring)
     PairLaunch pl;
+    std::vector<std::unique_ptr<PairLaunch>> mini;   // engine 3: mini-stripe launches without a band, one per row class (short patterns routed off the strips)
     DevBuf pair_res;
     uint64_t n_live = 0;            // pairs that reach a kernel (n > 0 and m > 0)
     std::vector<uint32_t> live_idx; // engine 2: pair index of descriptor k
@@ -689,7 +692,8 @@ int pwa_ctx_create(int device, pwa_ctx** out) {
             return PWA_E_HIP;
         }
     if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->copy_ev[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->copy_ev[1], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->copy_ev[1], hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->aux_ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->aux_ev[1], hipEventDisableTiming) != hipSuccess) {
         pwa_ctx_destroy(c);
         return PWA_E_HIP;
     }
@@ -706,6 +710,9 @@ void pwa_ctx_destroy(pwa_ctx* c) {
     for (auto& e : c->copy_ev)
         if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (auto& e : c->aux_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->band_cache) (void)hipFree(c->band_cache);
     if (c->sband_cache) (void)hipFree(c->sband_cache);
     if (c->hand_cache) (void)hipFree(c->hand_cache);
@@ -943,8 +950,27 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         }
     arena_bytes += 512;   // slack: strips and text words are over-read, never over-used
     if (arena_bytes >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "sequence arena exceeds 4 GiB");
+    const bool arena_coded = b->use_strips && score_path == SC_PERM;
+    // Short patterns that a scores pass routes away from the strips run on the mini-stripe engine WITHOUT a band (mini_fill.hip.h,
+    // BAND = false: four pairs per wave) where it applies: coded arena, keyed cells in range, table constants in a byte.
+    bool mini_scores = false, mini_gap0 = false;
+    if (arena_coded && !affine && !nwdist && !b->want_end && ctx->knobs.tb_engine != 0 && tb_range_ok(max_n + max_m, match, mismatch, gap)) {
+        const int64_t kdm = ((int64_t)match - gap) * 4 + 2, kdx = ((int64_t)mismatch - gap) * 4 + 2;
+        mini_scores = kdm <= 127 && kdm >= -126 && kdx <= 127 && kdx >= -126;
+        if (mini_scores && !local) {
+            const int64_t km = ((int64_t)match - 2 * (int64_t)gap) * 4 + 1, kx = ((int64_t)mismatch - 2 * (int64_t)gap) * 4 + 1;
+            const int64_t amax = std::max<int64_t>({std::llabs((long long)match), std::llabs((long long)mismatch), std::llabs((long long)gap), 1});
+            mini_gap0 = km <= 127 && km >= -126 && kx <= 127 && kx >= -126 && (max_n + max_m + 2) <= (1ull << 27) / (uint64_t)amax;
+        }
+    }
+    auto mini_rl_of = [&](uint64_t n) -> int {   // rows per lane of the mini-stripe class that holds an n-row pattern, 0: none
+        if (mini_scores && n <= 256)
+            for (const int rl : kMiniRL)
+                if (n <= (uint64_t)(16 * rl)) return rl;
+        return 0;
+    };
     {
-        const bool coded = b->use_strips && score_path == SC_PERM;
+        const bool coded = arena_coded;
         uint8_t code8[256];
         for (int v = 0; v < 256; ++v) code8[v] = (uint8_t)(code_of[v] >= 0 ? code_of[v] : 7);
         HIPC(ctx, b->arena.alloc(arena_bytes));
@@ -1089,7 +1115,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             const double vpc = (best_mode == BM_SWS ? 4.06 : best_mode == BM_SW ? 5.02 : best_mode == BM_NWG ? 2.53 : 4.5) + (score_path == SC_CMP ? 2.0 : 0.0);
             constexpr double kLoneNs = 1.9, kSimdNs = 1.63, kSimds = 1024.0;                // ns per wave instruction: one wave alone / a SIMD with two
             const double step_ns = local ? 105.0 : 75.0, lag_us = 9.0, lone_step_ns = 100.0;   // stripe engine: per step and SIMD; per stripe of pipeline lag
-            std::vector<double> I(nt0), S(nt0), L(nt0);   // strip instructions / stripe-engine steps / longest single-pair latency (us) of a task
+            std::vector<double> I(nt0), S(nt0), L(nt0);   // strip instructions / stripe-side work (ns x SIMD) / longest single-pair latency (us) of a task
             double I_total = 0;
             for (size_t t = 0; t < nt0; ++t) {
                 const uint64_t strips = (ht[t].maxlen + bestR - 1) / bestR;
@@ -1099,9 +1125,15 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
                 for (uint32_t l = 0; l < ht[t].count; ++l) {
                     const uint32_t k = order[ht[t].first + l];
                     const uint64_t n = slen(pair_a[k]), m = slen(pair_b[k]);
+                    if (const int mrl = mini_rl_of(n)) {   // mini-stripe engine, no band: a quarter of a wave, (17 + 5 | 8.5 RL) instructions per step
+                        const double mstep = (17.0 + (local ? 8.5 : 5.0) * mrl) * 1.37;   // [gpu] 92 ns per step for RL = 10, global (tools/probes/mini_mix.hip)
+                        steps += (double)(m + 15) * mstep / 4.0 / 1.5;                    // (two waves per SIMD: ~1.9 x one wave's throughput)
+                        lat = std::max(lat, (double)(m + 15) * mstep * 1e-3);
+                        continue;
+                    }
                     const PairGeom g = choose_geom(ctx->knobs, n);
                     const double stripes = (double)((n + 64 * g.rl - 1) / (64 * g.rl));
-                    steps += stripes * (double)(m + 63);
+                    steps += stripes * (double)(m + 63) * step_ns;
                     lat = std::max(lat, stripes * lag_us + (double)(m + 63) * lone_step_ns * 1e-3);
                 }
                 S[t] = steps;
@@ -1114,7 +1146,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
                 double best_t = -1, moved_I = 0, moved_S = 0, moved_L = 0;
                 for (size_t k = 0; k <= nt0; ++k) {
                     const double ts = std::max(sufmax[k] * kLoneNs, (I_total - moved_I) / kSimds * kSimdNs) * 1e-3;              // us
-                    const double tp = k ? std::max(moved_L, moved_S / kSimds * step_ns * 1e-3) + 15.0 : 0.0;                       // us (+ two more launches)
+                    const double tp = k ? std::max(moved_L, moved_S / kSimds * 1e-3) + 15.0 : 0.0;                                 // us (+ two more launches)
                     const double tt = ts + tp;
                     if (best_t < 0 || tt < best_t) {
                         best_t = tt;
@@ -1332,36 +1364,83 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
       }   // strips that stay
     }
     if (!live_pairs_engine.empty()) {
-        // ---- stripe engine, no traceback band: exact first-maximum end cells, any scoring
-        const std::vector<uint32_t>& plist = live_pairs_engine;
-        const size_t nl = plist.size();
-        b->use_pairs = true;
-        b->live_idx = plist;
-        std::vector<PairDesc> pd(nl);
-        uint64_t pe_max_n = 0;
-        for (const uint32_t k : plist) pe_max_n = std::max(pe_max_n, slen(pair_a[k]));
-        const PairGeom geom = choose_geom(ctx->knobs, pe_max_n);
+        // ---- the pairs that do not run on strips: short patterns over a coded arena on the mini-stripe engine (no band, four pairs per
+        // wave, one launch per row class), everything else on the stripe engine (no band: exact first-maximum end cells, any scoring)
+        std::vector<uint32_t> plist;
+        std::vector<std::pair<int, std::vector<uint32_t>>> mini_lists;   // (rows per lane, pairs)
+        for (const uint32_t k : live_pairs_engine) {
+            const int mrl = mini_rl_of(slen(pair_a[k]));
+            if (!mrl) {
+                plist.push_back(k);
+                continue;
+            }
+            size_t c = 0;
+            while (c < mini_lists.size() && mini_lists[c].first != mrl) ++c;
+            if (c == mini_lists.size()) mini_lists.emplace_back(mrl, std::vector<uint32_t>());
+            mini_lists[c].second.push_back(k);
+        }
+        const size_t nl = live_pairs_engine.size();
         HIPC(ctx, b->pair_res.alloc(nl * sizeof(PairResult)));
         HIPC(ctx, hipMemset(b->pair_res.p, 0, nl * sizeof(PairResult)));
-        for (size_t q = 0; q < nl; ++q) {
-            const uint32_t k = plist[q];
-            std::memset(&pd[q], 0, sizeof(PairDesc));
-            pd[q].pat = b->arena.as<uint8_t>() + aoff[pair_a[k]];
-            pd[q].txt = b->arena.as<uint8_t>() + aoff[pair_b[k]];
-            pd[q].n = (int32_t)slen(pair_a[k]);
-            pd[q].m = (int32_t)slen(pair_b[k]);
-            pd[q].res = b->pair_res.as<PairResult>() + q;
-            pd[q].out_index = k;
-            const uint64_t n = slen(pair_a[k]), m = slen(pair_b[k]);
-            b->padded_cells += (n + 64 * geom.rl - 1) / (64 * geom.rl) * (64 * geom.rl) * m;
-        }
-        {
+        size_t q_next = 0;
+        auto describe = [&](uint32_t k, size_t q) {
+            PairDesc d;
+            std::memset(&d, 0, sizeof d);
+            d.pat = b->arena.as<uint8_t>() + aoff[pair_a[k]];
+            d.txt = b->arena.as<uint8_t>() + aoff[pair_b[k]];
+            d.n = (int32_t)slen(pair_a[k]);
+            d.m = (int32_t)slen(pair_b[k]);
+            d.res = b->pair_res.as<PairResult>() + q;
+            d.out_index = k;
+            return d;
+        };
+        std::string names;
+        if (!plist.empty()) {
+            b->use_pairs = true;
+            b->live_idx = plist;
+            std::vector<PairDesc> pd;
+            pd.reserve(plist.size());
+            uint64_t pe_max_n = 0;
+            for (const uint32_t k : plist) pe_max_n = std::max(pe_max_n, slen(pair_a[k]));
+            const PairGeom geom = choose_geom(ctx->knobs, pe_max_n);
+            for (const uint32_t k : plist) {
+                pd.push_back(describe(k, q_next++));
+                b->padded_cells += (slen(pair_a[k]) + 64 * geom.rl - 1) / (64 * geom.rl) * (64 * geom.rl) * slen(pair_b[k]);
+            }
             const int rc = b->pl.build(ctx, pd, match, mismatch, gap, geom);
             if (rc != PWA_OK) return rc;
             b->pl.G.scores_out = b->scores.as<int32_t>();   // the device score vector is complete after run()
+            names = std::string("pair_fill_kernel<RL=") + std::to_string(geom.rl) + (local ? ",SW" : ",NW") + ",no-traceback>";
         }
-        const std::string pname = std::string("pair_fill_kernel<RL=") + std::to_string(geom.rl) + (local ? ",SW" : ",NW") + ",no-traceback>";
-        b->kernel_name = b->use_strips ? b->kernel_name + " + " + pname : pname;   // (the strip kernel first: bench.py prices its instruction mix)
+        for (auto& cls : mini_lists) {
+            const int rl = cls.first;
+            std::vector<uint32_t>& lst = cls.second;
+            std::stable_sort(lst.begin(), lst.end(), [&](uint32_t x, uint32_t y) { return slen(pair_b[x]) > slen(pair_b[y]); });   // a wave's four texts about equally long
+            std::vector<PairDesc> pd;
+            pd.reserve(lst.size() + 3);
+            for (const uint32_t k : lst) {
+                PairDesc d = describe(k, q_next++);
+                d.score_bias = mini_gap0 ? wrap_mul((int64_t)(slen(pair_a[k]) + slen(pair_b[k])), gap) : 0;
+                pd.push_back(d);
+                b->padded_cells += (uint64_t)(16 * rl) * slen(pair_b[k]);
+            }
+            const uint32_t n_real = (uint32_t)pd.size();
+            while (pd.size() % 4) {   // empty patterns fill the last wave (their results go nowhere: no row of theirs is row n)
+                PairDesc d = pd[n_real - 1];
+                d.n = 0;
+                pd.push_back(d);
+            }
+            b->mini.emplace_back(new PairLaunch());
+            PairLaunch& ml = *b->mini.back();
+            for (DevBuf* d : {&ml.desc, &ml.tasks, &ml.rows, &ml.progress, &ml.best, &ml.queue}) d->pool = ctx;
+            ml.perm = ml.keyed = true;
+            ml.gap0 = mini_gap0;
+            const int rc = ml.build_mini(ctx, pd, n_real, mini_gap0 ? match - 2 * gap : match, mini_gap0 ? mismatch - 2 * gap : mismatch, mini_gap0 ? 0 : gap, rl);
+            if (rc != PWA_OK) return rc;
+            ml.G.scores_out = b->scores.as<int32_t>();
+            names += std::string(names.empty() ? "" : " + ") + "mini_fill_kernel<RL=" + std::to_string(rl) + (local ? ",SW" : (mini_gap0 ? ",NW,GAP0" : ",NW")) + ",no-band>";
+        }
+        b->kernel_name = b->use_strips ? b->kernel_name + " + " + names : names;   // (the strip kernel first: bench.py prices its instruction mix)
     }
     if (dbg) {
         mark("engine setup");
@@ -1662,9 +1741,25 @@ int pwa_batch_run(pwa_batch* b, void* stream_v) {
             }
             HIPC(ctx, hipGetLastError());
         }
+        // the stripe launch of a split batch is often a few long pairs -- tens of waves bound by their own pipeline latency -- so the
+        // mini-stripe launches run NEXT to it, on the context's auxiliary stream, forked after the strips and joined before the end
+        const bool fork = b->use_pairs && !b->mini.empty();
+        hipStream_t ms = fork ? ctx->aux_stream : st;
+        if (fork) {
+            HIPC(ctx, hipEventRecord(ctx->aux_ev[0], st));
+            HIPC(ctx, hipStreamWaitEvent(ms, ctx->aux_ev[0], 0));
+        }
         if (b->use_pairs) {
             const int rc = b->pl.launch(ctx, st, b->mode == PWA_MODE_SW, false, false, nullptr);
             if (rc != PWA_OK) return rc;
+        }
+        for (auto& ml : b->mini) {
+            const int rc = ml->launch(ctx, ms, b->mode == PWA_MODE_SW, false, WALK_NONE, nullptr);
+            if (rc != PWA_OK) return rc;
+        }
+        if (fork) {
+            HIPC(ctx, hipEventRecord(ctx->aux_ev[1], ms));
+            HIPC(ctx, hipStreamWaitEvent(st, ctx->aux_ev[1], 0));
         }
     }
     HIPC(ctx, hipEventRecord(b->ev1[slot], st));
@@ -1687,6 +1782,7 @@ int pwa_batch_set_d_scores(pwa_batch* b, int32_t* d_scores) {
     b->ext_scores = d_scores;
     b->bp.scores = d_scores;
     b->pl.G.scores_out = d_scores;
+    for (auto& ml : b->mini) ml->G.scores_out = d_scores;
     return PWA_OK;
 }
 
@@ -1718,7 +1814,10 @@ int pwa_batch_info(const pwa_batch* b, uint64_t* cells, uint64_t* padded_cells, 
     if (!b) return PWA_E_INVALID;
     if (cells) *cells = b->cells;
     if (padded_cells) *padded_cells = b->padded_cells;
-    if (n_tasks) *n_tasks = (b->use_strips ? b->bp.n_tasks : 0) + (b->use_pairs ? b->live_idx.size() : 0);
+    if (n_tasks) {
+        *n_tasks = (b->use_strips ? b->bp.n_tasks : 0) + (b->use_pairs ? b->live_idx.size() : 0);
+        for (const auto& ml : b->mini) *n_tasks += ml->G.n_tasks;
+    }
     if (kernel_name) *kernel_name = b->kernel_name.c_str();
     return PWA_OK;
 }
