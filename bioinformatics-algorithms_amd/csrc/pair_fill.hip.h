@@ -1115,14 +1115,18 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
             }
         }
         const int ii = i - lane, jj = j - lane;
-        int code = 0xff;                                                 // 0xff: not available in this trip
-        if (ii > 0 && jj > 0) {
-            const unsigned q = (unsigned)(ii - 1);
-            const int s = Geo::stripe(q), ql = Geo::row_in_stripe(q);
-            const int t = jj - 1 + Geo::lane(ql);
-            const int w = t / WIN;
-            if (s == cur_s && w == cur_w) code = win[cb * WB + (t - w * WIN) * STEP_BYTES + Geo::off(ql)];
-        }
+        auto code_at = [&](int ci, int cj) -> int {                      // code of cell (ci, cj); 0xff: outside the matrix or the staged window
+            int c = 0xff;
+            if (ci > 0 && cj > 0) {
+                const unsigned q = (unsigned)(ci - 1);
+                const int s = Geo::stripe(q), ql = Geo::row_in_stripe(q);
+                const int t = cj - 1 + Geo::lane(ql);
+                const int w = t / WIN;
+                if (s == cur_s && w == cur_w) c = win[cb * WB + (t - w * WIN) * STEP_BYTES + Geo::off(ql)];
+            }
+            return c;
+        };
+        const int code = code_at(ii, jj);
         const unsigned long long dm = __ballot(code == TB_DIAG);
         const int L = (~dm == 0ull) ? 64 : __builtin_ctzll(~dm);        // leading run of diagonal moves
         if (OPS && lane < L) ops[cnt + lane] = 'M';                      // hw2.cpp:164-169 / 240-245
@@ -1150,16 +1154,25 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         j -= L;
         if (L < 64) {
             const int c2 = __builtin_amdgcn_readlane(code, L);
-            if (c2 == TbCode<LOCAL>::UP) {                               // hw2.cpp:170-174 / 246-250
-                if (OPS && lane == 0) ops[cnt] = 'D';
+            if (c2 == TbCode<LOCAL>::UP || c2 == TbCode<LOCAL>::LEFT) {  // hw2.cpp:170-179 / 246-255
+                const bool left = c2 == TbCode<LOCAL>::LEFT;
+                if (OPS && lane == 0) ops[cnt] = left ? 'I' : 'D';
                 ++cnt;
-                --i;
+                i -= left ? 0 : 1;
+                j -= left ? 1 : 0;
                 run = 0;
-            } else if (c2 == TbCode<LOCAL>::LEFT) {                      // hw2.cpp:175-179 / 251-255
-                if (OPS && lane == 0) ops[cnt] = 'I';
-                ++cnt;
-                --j;
-                run = 0;
+                // r03: a RUN of gaps in that direction in the same trip -- the lanes look along the row (left) or the column (up) behind the
+                // gap: a global alignment of a 150-row pattern against 2000 columns is mostly a few long runs of 'l', which this loop used to
+                // take one op per LDS round trip ([gpu] hw2_amd -g, 262 144 pairs 150 x 2000: walks ~29 -> 17 ms of device time; what is left
+                // is one 64-step window per trip, fetched at LDS-DMA latency)
+                if (OVL && i > 0 && j > 0) {
+                    const int rcode = left ? code_at(i, j - lane) : code_at(i - lane, j);
+                    const unsigned long long gm = __ballot(rcode == c2);
+                    const int R = (~gm == 0ull) ? 64 : __builtin_ctzll(~gm);
+                    cnt += R;
+                    i -= left ? 0 : R;
+                    j -= left ? R : 0;
+                }
             } else if (LOCAL && c2 == TB_STOP) {                         // dp == 0, hw2.cpp:239
                 stopped = true;
                 break;

@@ -1897,9 +1897,9 @@ static uint64_t arena_limit(const pwa_ctx* ctx) {
 // scheduled, coded and uploaded (copy stream, page-locked pieces) and its kernels are queued behind; the host then collects run k.
 // Destroyed runs hand their device buffers to the context's free list (no hipFree: it would wait for the run in flight).
 // Cutting a list that FITS one arena into several runs, so that the first kernels start before all of the input is on the device, was
-// built and measured (PWA_PIPE_RUNS=6) and is not the default: [gpu] hw2_amd -l on 262 144 pairs 150 x 2000 (569 MB): scores pass 87 ms in
-// one run, 116 ms in six -- the kernels of that input take 9 ms, the rest is host work per run (alphabet scans, sorts, uploads with their
-// synchronisations), which six runs pay six times; 4.5 GB (two arenas): 348 ms in two pipelined runs, 477 ms in six
+// built and measured (PWA_PIPE_RUNS=6) and is not the default: [gpu] hw2_amd -l on 262 144 pairs 150 x 2000 (569 MB): scores pass 89 ms in
+// one run, 137 ms in six -- the kernels of that input take 9 ms, the rest is host work per run (alphabet scans, sorts, uploads with their
+// synchronisations), which six runs pay six times; 4.5 GB (two arenas): 357 ms in two pipelined runs, 493 ms in six
 // (profiles/r03_cli_scale.txt).
 template <class Create>
 static int scores_in_arena_chunks(pwa_ctx* ctx, const uint64_t* seq_off, uint32_t n_seq, const uint32_t* pair_a, const uint32_t* pair_b,

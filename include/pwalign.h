@@ -27,9 +27,10 @@
  *   stripe engine      one wave per 64 RL rows of a pair, anti-diagonal front, stripes pipelined (pair_fill.hip.h): traceback fills
  *                      of long patterns, scores with end cells, and -- by estimated cost -- the scores of pairs that would leave the
  *                      strip engine's waves under-filled (a few long pairs);
- *   mini-stripe engine 16 lanes per pair, four pairs per wave (mini_fill.hip.h): traceback fills of patterns of up to 256 rows.
- *   pwa_align_batch / pwa_overlaps pick the band geometry pair by pair; pwa_scores / pwa_batch_create split a list between the strip
- *   and the stripe engine.
+ *   mini-stripe engine 16 lanes per pair, four pairs per wave (mini_fill.hip.h): traceback fills of patterns of up to 256 rows, and --
+ *                      without a band -- the scores of such pairs when a scores pass routes them off the strips.
+ *   pwa_align_batch / pwa_overlaps pick the band geometry pair by pair; pwa_scores / pwa_batch_create split a list between the three
+ *   engines by estimated cost.
  *
  * Environment switches (tests and diagnostics only).  They are read ONCE, by pwa_ctx_create, into the context; no other entry point
  * consults the environment, so a process that wants another setting creates another context.  (pwa_fasta_read, which has no context,
