@@ -393,9 +393,11 @@ struct PairGeom {
 PairGeom choose_geom(const Knobs& kn, uint64_t max_n, bool keyed = true, bool keyed_tb = false) {
     // (W = 3 -- three stripes + the helper = one wave per SIMD -- was measured in r02: no gain over W = 4, the stripes behind the
     // first workgroup run ~5-9 % slower than the first either way: they run at the edge of what their producer has posted.)
-    PairGeom g{max_n <= 32768 ? 2 : 4, 4};   // [gpu] 10k x 10k: RL=2 2.27 ms vs RL=4 2.52; 100k x 100k: RL=4 20.9 ms vs RL=2 22.0
-    // 129..256 rows: ONE 256-row stripe (W = 1, 8 workgroups per CU) instead of two 128-row stripes in a 4-stripe
-    // workgroup with two idle waves; [gpu] 4096 pairs 150 x 10k: fill 8.2 -> 7.3 ms, with the score band 12.1 -> 10.4 ms
+    // RL = 2 up to 32k rows (twice the stripes = twice the waves of a pair in flight), RL = 4 beyond.  (The choice was measured in r01 --
+    // 10k x 10k: RL = 2 10 % ahead; 100k x 100k: RL = 4 5 % ahead -- and has held since; today's fills: 1.65 ms / 11.8 - 12.2 ms)
+    PairGeom g{max_n <= 32768 ? 2 : 4, 4};
+    // 129..256 rows: ONE 256-row stripe (W = 1) instead of two 128-row stripes in a 4-stripe workgroup with two idle waves.  (Since r03
+    // only what the mini-stripe engine cannot take comes here with such patterns: alphabets of more than 7 symbols, scores beyond the keys.)
     if (max_n > 128 && max_n <= 256) g.rl = 4;
     if (kn.force_rl) g.rl = kn.force_rl == 2 ? 2 : 4;   // experiments only
     if (!keyed) g.rl = 4;   // the plain int32 traceback form exists for RL = 4 only (pair_kernels.hip)
@@ -1869,6 +1871,12 @@ int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint3
 void pwa_batch_destroy(pwa_batch* b) {
     if (!b) return;
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    // the device buffers go back to the context's free list, not to hipFree (which would wait for the whole device): wait here for
+    // this batch's own last run, so that the next batch cannot be handed memory a kernel is still using
+    if (b->ran && b->n_runs) {
+        const int slot = (int)((b->n_runs - 1) % pwa_batch::kRing);
+        if (b->ev1[slot]) (void)hipEventSynchronize(b->ev1[slot]);
+    }
     for (int e = 0; e < pwa_batch::kRing; ++e) {
         if (b->ev0[e]) (void)hipEventDestroy(b->ev0[e]);
         if (b->ev1[e]) (void)hipEventDestroy(b->ev1[e]);
