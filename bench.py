@@ -674,8 +674,14 @@ def bench_global_batch(args, pkg, ctx, rank=0, world=1, dist=None, torch=None, d
     alg_bytes = cells * (5 if bands else 1) + sum(len(x) for x in seqs)
     written = float(st["band_bytes"])
     rl = next((r for r in (4, 6, 8, 10, 12, 16) if plen <= 16 * r), None)
-    kern = ("mini_fill_kernel<RL=%d,%s%s>" % (rl, "SW,SBAND" if bands else "NW,GAP0", "") if rl else
-            "pair_fill_kernel<RL=%d,W=4,%s,TB%s,PERM%s>" % (2 if plen <= 32768 else 4, mode.upper(), ",SBAND" if bands else "", "" if bands else ",GAP0"))
+    stripes_only = os.environ.get("PWA_TB_ENGINE") == "0"
+    if rl and not stripes_only:       # four pairs per wave
+        kern = "mini_fill_kernel<RL=%d,%s>" % (rl, "SW,SBAND" if bands else "NW,GAP0")
+    elif plen <= 1024 and n_pairs >= 256 and not stripes_only:   # one pair per wave
+        kern = "mini_fill_kernel<RL=%d,LN=64,%s>" % (6 if plen <= 384 else 8 if plen <= 512 else 12 if plen <= 768 else 16, "SW,SBAND" if bands else "NW,GAP0")
+    else:
+        kern = "pair_fill_kernel<RL=%d,W=%d,%s,TB%s,PERM%s>" % (4 if 128 < plen <= 256 or plen > 32768 else 2, 1 if plen <= 256 else 4, mode.upper(),
+                                                                 ",SBAND" if bands else "", "" if bands else ",GAP0")
     line = {
         "metric": "GCUPS (billion DP cells/s) %s full alignments of a pair batch (-g shape); bit-exact vs hw2.cpp" % mode.upper(),
         "value": cells * world * args.steps / elapsed / 1e9, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

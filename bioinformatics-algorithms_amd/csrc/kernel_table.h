@@ -36,7 +36,8 @@ pair_kernel_t pair_traceback_kernel_for(int rl, bool local, int walk);   // walk
 // mini_kernels*.hip -- the mini-stripe engine (16 lanes per pair, 4 pairs per wave; keyed cells, table scoring): fills for
 // rl in kMiniRL; gap0 only global without score band; the walks over its band geometry (BandGeo<16, rl>)
 constexpr int kMiniRL[] = {4, 6, 8, 10, 12, 16};
-pair_kernel_t mini_fill_kernel_for(int rl, bool local, bool sband, bool gap0, bool band = true);   // band = false: scores (+ end cells) only
-pair_kernel_t mini_traceback_kernel_for(int rl, bool local, int walk);
+// ln = 16: four pairs per wave (rl in kMiniRL); ln = 64: one pair per wave, rl = 8 | 16 (single stripes of 512 / 1024 rows; band only)
+pair_kernel_t mini_fill_kernel_for(int rl, bool local, bool sband, bool gap0, bool band = true, int ln = 16);   // band = false: scores (+ end cells) only
+pair_kernel_t mini_traceback_kernel_for(int rl, bool local, int walk, int ln = 16);
 
 }  // namespace pwa

@@ -39,38 +39,46 @@ __host__ __device__ inline size_t mini_band_steps(size_t m) { return (m + 15 + 1
 typedef uint32_t mu32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t mu32x4 __attribute__((ext_vector_type(4)));
 
-// lanes 1..15 of every row <- lane k-1 of v; lane 0 of every row keeps dst
-__device__ __forceinline__ int mini_row_shr1(int dst, int v) { return __builtin_amdgcn_update_dpp(dst, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false); }
-// lane 0 of every row <- lane Q of v in that row (lanes 4, 8, 12 are written too and overwritten by the row_shr:1 that follows)
-template <int Q>
+// LN = 16: lanes 1..15 of every row <- lane k-1 of v, lane 0 of every row keeps dst (row_shr:1);  LN = 64 (one pair per wave): lanes
+// 1..63 <- lane k-1, lane 0 keeps dst (wave_shr:1)
+template <int LN = 16>
+__device__ __forceinline__ int mini_row_shr1(int dst, int v) {
+    if constexpr (LN == 16) return __builtin_amdgcn_update_dpp(dst, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    else return __builtin_amdgcn_update_dpp(dst, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+// lane 0 of every row (LN = 64: of row 0 only) <- lane Q of v in that row (lanes 4, 8, 12 are written too and overwritten by the shift
+// that follows)
+template <int Q, int LN = 16>
 __device__ __forceinline__ int mini_pick_lane0(int dst, int v) {
-    if constexpr (Q == 0) return __builtin_amdgcn_update_dpp(dst, v, 0xE4 /* quad_perm:[0,1,2,3] */, 0xf, 0x1, false);
-    else return __builtin_amdgcn_update_dpp(dst, v, 0x100 + Q /* row_shl:Q */, 0xf, 0x1, false);
+    constexpr int ROWS = LN == 16 ? 0xf : 0x1;
+    if constexpr (Q == 0) return __builtin_amdgcn_update_dpp(dst, v, 0xE4 /* quad_perm:[0,1,2,3] */, ROWS, 0x1, false);
+    else return __builtin_amdgcn_update_dpp(dst, v, 0x100 + Q /* row_shl:Q */, ROWS, 0x1, false);
 }
 
 // 16 steps of four pairs.  GUARD: some lane of the wave is outside its matrix at some step of the chunk (the first 15
 // steps, and from the shortest text's last column on): that lane's state is frozen (pair_fill.hip.h, keyed_chunk).
-template <int RL, bool LOCAL, bool SBAND, bool GUARD, bool GAP0, bool BAND = true>
+template <int RL, bool LOCAL, bool SBAND, bool GUARD, bool GAP0, bool BAND = true, int LN = 16>
 __device__ __forceinline__ void mini_chunk(const int t0, const int k, const int m, const uint32_t (&pk)[(RL + 3) / 4], int (&hl)[RL], int& diag0,
                                            int& bottom, int& tch, const int tcv, const int top0, const int top_inc, int (&bs)[RL], int (&bj)[RL],
                                            const uint32_t tab_lo, const uint32_t tab_hi, const int cl, g_u8* const tba, g_u8* const tbb,
                                            g_i32* const sb) {
-    typedef BandGeo<16, RL> Geo;
+    typedef BandGeo<LN, RL> Geo;
     constexpr int NQ = (RL + 3) / 4;
     constexpr int PU = TbCode<LOCAL>::UP, PL = TbCode<LOCAL>::LEFT;
     static_assert(!GAP0 || (!LOCAL && !SBAND && PU == 0), "gap-shifted fills: global, no score band");
+    static_assert(LN == 16 || (LN == 64 && (RL == 6 || RL == 8 || RL == 12 || RL == 16)), "one pair per wave: single stripes of 384 .. 1024 rows");
     const int cu = p_addw(cl, PU - PL);
     static_for<0, 16>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         const int j = t0 + q - k + 1;
         const bool act = !GUARD || (unsigned)(j - 1) < (unsigned)m;   // this lane's column is inside its pair's matrix
         // text symbol (splatted): lane 0 of each row takes the staged symbol of step q, lane k the one lane k-1 had a step ago
-        const int tn = mini_row_shr1(mini_pick_lane0<q>(tch, tcv), tch);
+        const int tn = mini_row_shr1<LN>(mini_pick_lane0<q, LN>(tch, tcv), tch);
         uint32_t s4[NQ];
 #pragma unroll
         for (int x = 0; x < NQ; ++x) s4[x] = __builtin_amdgcn_perm(tab_hi, tab_lo, pk[x] ^ (uint32_t)tn);
         // the row above: lane k-1's last row of the previous step; lane 0 of each row: the matrix's row 0 (hw2.cpp:131-136 / 193)
-        const int up_in = mini_row_shr1(top0 + q * top_inc, bottom);
+        const int up_in = mini_row_shr1<LN>(top0 + q * top_inc, bottom);
         int dg = diag0, up = up_in;
         uint32_t codes[NQ];
         int hsb[RL];
@@ -111,9 +119,9 @@ __device__ __forceinline__ void mini_chunk(const int t0, const int k, const int 
         if constexpr (Geo::PA == 16) PWA_BAND_STORE((PWA_GLOBAL mu32x4*)(tba + q * Geo::SR), (mu32x4{codes[0], codes[1], codes[2], codes[3]}));
         if constexpr (Geo::PB == 2) PWA_BAND_STORE((PWA_GLOBAL uint16_t*)(tbb + q * Geo::SR), (uint16_t)codes[Geo::PA / 4]);
         if constexpr (Geo::PB == 4) PWA_BAND_STORE((g_u32*)(tbb + q * Geo::SR), codes[Geo::PA / 4]);
-        if (SBAND) {
+        if (SBAND) {   // (sb: the pair's int32 band at step t0; rows in quads [quad][lane][4]: Geo::sband_off)
 #pragma unroll
-            for (int r = 0; r < RL; ++r) sb[q * Geo::SR + r] = hsb[r];
+            for (int r = 0; r < RL; ++r) sb[q * Geo::SR + Geo::sband_off(k, r)] = hsb[r];
         }
         }
     });
@@ -128,13 +136,17 @@ __device__ __forceinline__ void mini_chunk(const int t0, const int k, const int 
 // BAND = false: the same fill without any band -- scores (and, local, the first-maximum end cell) of short-pattern pairs that a scores
 // pass routes away from the strip engine (pwalign.hip, batch_create_impl): four pairs per wave instead of one 256-row stripe per pair.
 constexpr int kMiniWaves = 4;
-template <int RL, bool LOCAL, bool SBAND, bool GAP0, bool BAND = true>
+// LN = 64 (r03): ONE pair per wave, lane k owns RL = 6 | 8 | 12 | 16 rows -- a single stripe of 384 .. 1024 rows (BandGeo<64, RL>: for RL = 8
+// and 16 the stripe engine's own layout [step][64 lanes][RL]), for batches of mid-sized patterns: one wave and 17 + 5 RL instructions per
+// step where the stripe engine runs 3 - 8 pipelined stripes of 33 with their hand-offs.
+template <int RL, bool LOCAL, bool SBAND, bool GAP0, bool BAND = true, int LN = 16>
 __global__ __launch_bounds__(64 * kMiniWaves) void mini_fill_kernel(const PairParams G) {
     static_assert(BAND || !SBAND, "no score band without the code band");
-    typedef BandGeo<16, RL> Geo;
+    typedef BandGeo<LN, RL> Geo;
     constexpr int NQ = (RL + 3) / 4;
+    constexpr int PPW = 64 / LN;   // pairs per wave
     constexpr int PU = TbCode<LOCAL>::UP, PL = TbCode<LOCAL>::LEFT;
-    const int lane = threadIdx.x & 63, k = lane & 15, grp = lane >> 4;
+    const int lane = threadIdx.x & 63, k = lane & (LN - 1), grp = lane / LN;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int match = G.match, mismatch = G.mismatch, gap = G.gap;
     // key constants (pair_fill.hip.h): diagonal (s - gap) * 4 + (prio(diag) - prio(left)), left gap * 4 + prio(left); as a byte table
@@ -147,15 +159,19 @@ __global__ __launch_bounds__(64 * kMiniWaves) void mini_fill_kernel(const PairPa
     // tasks of a round are about equally long, and a queue could not move a 1.3 ms task anyway).
     for (uint32_t tid = blockIdx.x * kMiniWaves + wave; tid < G.n_tasks; tid += gridDim.x * kMiniWaves) {
         // this row's pair (the host pads the descriptor list to whole tasks with empty patterns on a dump band)
-        const PWA_GLOBAL PairDesc* const P = (const PWA_GLOBAL PairDesc*)(G.pairs + (size_t)tid * 4 + grp);
+        const PWA_GLOBAL PairDesc* const P = (const PWA_GLOBAL PairDesc*)(G.pairs + (size_t)tid * PPW + grp);
         const int n = P->n, m = P->m;
         g_cu8* const pat = (g_cu8*)P->pat;
-        int mmax = max(m, __shfl_xor(m, 16)), mmin = min(m, __shfl_xor(m, 16));
-        mmax = max(mmax, __shfl_xor(mmax, 32));
-        mmin = min(mmin, __shfl_xor(mmin, 32));
+        int mmax = m, mmin = m;
+        if (PPW == 4) {
+            mmax = max(m, __shfl_xor(m, 16));
+            mmin = min(m, __shfl_xor(m, 16));
+            mmax = max(mmax, __shfl_xor(mmax, 32));
+            mmin = min(mmin, __shfl_xor(mmin, 32));
+        }
         mmax = __builtin_amdgcn_readfirstlane(mmax);
         mmin = __builtin_amdgcn_readfirstlane(mmin);
-        const int n_chunks = (mmax + 15 + 15) / 16;
+        const int n_chunks = (mmax + (LN - 1) + 15) / 16;
         const int i_first = k * RL + 1;   // first row of this lane (1-based)
         uint32_t pk[NQ];
         int hl[RL], bs[RL], bj[RL];
@@ -178,49 +194,49 @@ __global__ __launch_bounds__(64 * kMiniWaves) void mini_fill_kernel(const PairPa
         const int top_inc = (LOCAL || GAP0) ? 0 : (int)((unsigned)gap * 4u);
         g_u8* const tb = (g_u8*)P->tb;
         g_i32* const sband = SBAND ? (g_i32*)P->sband : nullptr;
-        const int offa = k * Geo::PA, offb = 16 * Geo::PA + k * Geo::PB;
+        const int offa = k * Geo::PA, offb = LN * Geo::PA + k * Geo::PB;
         int bottom = 0, tch = 0;
         // Text staging WITHOUT vector-memory loads: a single VMEM load in the chunk loop makes the wave wait, at every chunk, for all the
         // band stores issued before it (loads and stores share vmcnt and return in order) -- [gpu, r03] 3.8 ms instead of 1.5 ms for the
         // 4096 x (150 x 10k) batch.  The four texts are read with SCALAR loads (16 bytes per pair and chunk, a chunk ahead; lgkmcnt) and
         // each lane picks its byte: dword (lane >> 2) of the 16 loaded, byte (lane & 3) of it.
-        const uint32_t* tg[4];
-        int mg[4];
+        const uint32_t* tg[PPW];
+        int mg[PPW];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
+        for (int x = 0; x < PPW; ++x) {
             const uint64_t tp = (uint64_t)(uintptr_t)P->txt;
-            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)tp, 16 * x), hi = __builtin_amdgcn_readlane((uint32_t)(tp >> 32), 16 * x);
+            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)tp, LN * x), hi = __builtin_amdgcn_readlane((uint32_t)(tp >> 32), LN * x);
             tg[x] = (const uint32_t*)(uintptr_t)(((uint64_t)hi << 32) | lo);
-            mg[x] = __builtin_amdgcn_readlane(m, 16 * x);
+            mg[x] = __builtin_amdgcn_readlane(m, LN * x);
         }
-        auto stage = [&](int t0s, mu32x4 (&w)[4]) {   // bytes t0s .. t0s+15 of every pair's text (clamped: never more than 31 bytes past its end)
+        auto stage = [&](int t0s, mu32x4 (&w)[PPW]) {   // bytes t0s .. t0s+15 of every pair's text (clamped: never more than 31 bytes past its end)
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
+            for (int x = 0; x < PPW; ++x) {
                 const int tc = min(t0s, (mg[x] + 15) & ~15);
                 w[x] = *(const __attribute__((address_space(4))) mu32x4*)((uintptr_t)tg[x] + (size_t)tc);
             }
         };
         const uint32_t bsel = (uint32_t)(k & 3) * 0x01010101u;   // v_perm selector: byte (k & 3) of the dword, in all four bytes
-        const int wsel = lane >> 2;
-        mu32x4 wnext[4];
+        const int wsel = lane >> 2;   // (LN = 64: only lanes 0..15 -- the ones the per-step pick reads -- need their dword)
+        mu32x4 wnext[PPW];
         stage(0, wnext);
         for (int ch = 0; ch < n_chunks; ++ch) {
             const int t0 = ch * 16;
             uint32_t wv = wnext[0][0];
 #pragma unroll
-            for (int x = 1; x < 16; ++x) wv = (wsel == x) ? wnext[x >> 2][x & 3] : wv;
+            for (int x = 1; x < 4 * PPW; ++x) wv = (wsel == x) ? wnext[x >> 2][x & 3] : wv;
             const int tcv = (int)__builtin_amdgcn_perm(wv, wv, bsel);   // lane q of a row: its pair's column t0 + q, splatted (the symbol travels down the lanes that way)
             stage(t0 + 16, wnext);                                       // a chunk ahead
             const int top0 = tb_stored(LOCAL || GAP0 ? 0 : p_mulw(t0 + 1, gap), gap, PU);
             g_u8* const tbs = tb + (size_t)t0 * Geo::SR;
-            g_i32* const sbs = SBAND ? sband + (size_t)t0 * Geo::SR + k * RL : nullptr;
-            const bool interior = t0 >= 15 && t0 + 16 <= mmin;   // every lane of every pair inside its matrix
+            g_i32* const sbs = SBAND ? sband + (size_t)t0 * Geo::SR : nullptr;
+            const bool interior = t0 >= LN - 1 && t0 + 16 <= mmin;   // every lane of every pair inside its matrix
             if (interior)
-                mini_chunk<RL, LOCAL, SBAND, false, GAP0, BAND>(t0, k, m, pk, hl, diag0, bottom, tch, tcv, top0, top_inc, bs, bj, tab_lo, tab_hi, cl,
-                                                                tbs + offa, tbs + offb, sbs);
+                mini_chunk<RL, LOCAL, SBAND, false, GAP0, BAND, LN>(t0, k, m, pk, hl, diag0, bottom, tch, tcv, top0, top_inc, bs, bj, tab_lo, tab_hi, cl,
+                                                                    tbs + offa, tbs + offb, sbs);
             else
-                mini_chunk<RL, LOCAL, SBAND, true, GAP0, BAND>(t0, k, m, pk, hl, diag0, bottom, tch, tcv, top0, top_inc, bs, bj, tab_lo, tab_hi, cl,
-                                                               tbs + offa, tbs + offb, sbs);
+                mini_chunk<RL, LOCAL, SBAND, true, GAP0, BAND, LN>(t0, k, m, pk, hl, diag0, bottom, tch, tcv, top0, top_inc, bs, bj, tab_lo, tab_hi, cl,
+                                                                   tbs + offa, tbs + offb, sbs);
         }
         PWA_GLOBAL PairResult* const res = (PWA_GLOBAL PairResult*)P->res;
         if (!LOCAL) {
@@ -242,7 +258,7 @@ __global__ __launch_bounds__(64 * kMiniWaves) void mini_fill_kernel(const PairPa
                 }
             }
 #pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) {
+            for (int off = LN / 2; off >= 1; off >>= 1) {
                 const int so = __shfl_xor(s_best, off), io = __shfl_xor(i_best, off), jo = __shfl_xor(j_best, off);
                 const bool better = so > s_best || (so == s_best && so > 0 && io < i_best);
                 if (better) {

@@ -10,7 +10,9 @@ static pair_kernel_t mini_fill_pick(bool local, bool sband, bool gap0) {
     return sband ? mini_fill_kernel<RL, false, true, false> : mini_fill_kernel<RL, false, false, false>;
 }
 pair_kernel_t mini_scores_kernel_for(int rl, bool local, bool gap0);   // mini_kernels_noband.hip
-pair_kernel_t mini_fill_kernel_for(int rl, bool local, bool sband, bool gap0, bool band) {
+pair_kernel_t mini_wide_kernel_for(int rl, bool local, bool sband, bool gap0);   // mini_kernels_wide.hip
+pair_kernel_t mini_fill_kernel_for(int rl, bool local, bool sband, bool gap0, bool band, int ln) {
+    if (ln == 64) return band ? mini_wide_kernel_for(rl, local, sband, gap0) : nullptr;
     if (!band) return sband ? nullptr : mini_scores_kernel_for(rl, local, gap0);
     switch (rl) {
         case 4: return mini_fill_pick<4>(local, sband, gap0);

@@ -12,7 +12,9 @@ static pair_kernel_t mini_tb_pick(bool local, int walk) {
     return walk == WALK_OPS ? pair_traceback_kernel<RL, false, WALK_OPS, 16>
            : walk == WALK_OVERLAP ? pair_traceback_kernel<RL, false, WALK_OVERLAP, 16> : pair_traceback_kernel<RL, false, WALK_NONE, 16>;
 }
-pair_kernel_t mini_traceback_kernel_for(int rl, bool local, int walk) {
+pair_kernel_t mini_wide_traceback_kernel_for(int rl, bool local, int walk);   // mini_kernels_wide.hip
+pair_kernel_t mini_traceback_kernel_for(int rl, bool local, int walk, int ln) {
+    if (ln == 64) return mini_wide_traceback_kernel_for(rl, local, walk);
     switch (rl) {
         case 4: return mini_tb_pick<4>(local, walk);
         case 6: return mini_tb_pick<6>(local, walk);

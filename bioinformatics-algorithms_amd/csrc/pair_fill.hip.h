@@ -791,22 +791,28 @@ enum { WALK_NONE = 0, WALK_OPS = 1, WALK_OVERLAP = 2 };   // end cells only / op
 template <int LN, int RL>
 struct BandGeo {
     static constexpr int SR = LN * RL;   // rows per stripe = bytes per band step
-    static constexpr int PA = LN == 64 ? RL : (RL >= 16 ? 16 : (RL >= 8 ? 8 : 4)), PB = RL - PA;
-    static_assert(LN == 64 || (LN == 16 && RL >= 4 && RL <= 16 && (PB == 0 || PB == 2 || PB == 4)), "band geometry");
+    static constexpr int PA = RL < 4 ? RL : (RL >= 16 ? 16 : (RL >= 8 ? 8 : 4)), PB = RL - PA;   // (RL = 2, 4, 8, 16: one plane, [lane][RL])
+    static_assert((LN == 64 || LN == 16) && RL >= 2 && RL <= 16 && (PB == 0 || PB == 2 || PB == 4), "band geometry");
     __host__ __device__ static inline int stripe(unsigned q) { return (int)(q / (unsigned)SR); }
     __host__ __device__ static inline int row_in_stripe(unsigned q) { return (int)(q % (unsigned)SR); }
     __host__ __device__ static inline int lane(int ql) { return (int)((unsigned)ql / (unsigned)RL); }
     __host__ __device__ static inline int off(int ql) {   // byte of the cell inside its step
-        if (LN == 64) return ql;
+        if (PB == 0) return ql;
         const int k = (int)((unsigned)ql / (unsigned)RL), r = ql - k * RL;
         return r < PA ? k * PA + r : LN * PA + k * PB + (r - PA);
+    }
+    // int32 score band of the mini-stripe kernels, per step: quads of rows [RL / 4][LN lanes][4] and, for RL % 4 = 2, a tail [LN][2] --
+    // every store instruction of a wave then writes ONE contiguous run (16 bytes per lane), whatever RL
+    __host__ __device__ static inline int sband_off(int k, int r) {
+        return r < (RL & ~3) ? (r >> 2) * (LN * 4) + k * 4 + (r & 3) : (RL & ~3) * LN + k * (RL & 3) + (r & 3);
     }
 };
 
 template <int RL, bool LOCAL, int WALK, int LN = 64>
 __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) {
     typedef BandGeo<LN, RL> Geo;
-    constexpr int WIN = 64;                        // steps per LDS window
+    constexpr int WIN = LN * RL <= 256 ? 64 : (LN * RL <= 512 ? 32 : 16);   // steps per LDS window: 64, or the power of two that keeps a window <= 16 KiB
+    static_assert((WIN & (WIN - 1)) == 0 && WIN * LN * RL <= 16384 && (WIN * LN * RL) % 1024 == 0, "window steps");
     constexpr int STEP_BYTES = LN * RL;
     constexpr int WB = WIN * STEP_BYTES;           // bytes per window (16 KiB for RL = 4)
     __shared__ __attribute__((aligned(16))) uint8_t win[WALK != WALK_NONE ? 2 * WB + 16 : 16];   // + a byte that reads "no code"

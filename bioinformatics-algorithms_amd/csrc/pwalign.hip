@@ -76,8 +76,8 @@ struct Knobs {
     int pipe_runs = 0;                          // PWA_PIPE_RUNS=N: cut a list that fits one arena into N pipelined runs (experiment; measured slower)
     int scores_route = -1;                      // PWA_SCORES_ROUTE: 0 = every pair on the strip engine, 1 = every pair on the stripe
                                                 // engine, unset = by estimated cost (batch_create_impl)
-    int tb_engine = -1;                         // PWA_TB_ENGINE: 0 = stripe engine only, 1 = mini-stripe engine wherever it applies,
-                                                // unset = by pattern length
+    int tb_engine = -1;                         // PWA_TB_ENGINE: 0 = stripe engine only, 2 = mini-stripe kernels wherever they exist (also one
+                                                // pair per wave for 257 .. 1024 rows, however few such pairs), unset = by pattern length and count
     void read() {
         auto flag = [](const char* n) { return std::getenv(n) != nullptr; };
         auto num = [](const char* n, int dflt) { const char* e = std::getenv(n); return e ? std::atoi(e) : dflt; };
@@ -434,7 +434,8 @@ struct PairLaunch {
     }
     PairParams G{};
     PairGeom geom{4, 4};
-    bool mini = false;   // the mini-stripe engine (mini_fill.hip.h): 16 lanes per pair, geom.rl rows per lane, 4 pairs per wave
+    bool mini = false;   // the mini-stripe engine (mini_fill.hip.h): mini_ln lanes per pair, geom.rl rows per lane, 64 / mini_ln pairs per wave
+    int mini_ln = 16;
     bool perm = false;   // sequences are coded 0..6 (pad 7) and the key constants fit a byte: table-scoring fill kernels
     bool keyed = true;   // traceback fills keep H * 4 + priority (needs |H| < 2^28); false: plain int32 compare-and-select form
     bool gap0 = false;   // global keyed table-scoring fill in gap-shifted coordinates: build() was given gap 0 and scores s - 2 gap
@@ -508,13 +509,15 @@ struct PairLaunch {
     }
     // mini-stripe engine: pd = the real pairs first (n_real of them), then empty patterns up to a multiple of four; task t = the
     // pairs 4t .. 4t+3 (the caller orders them so that a task's texts are about equally long)
-    int build_mini(pwa_ctx* ctx, std::vector<PairDesc>& pd, uint32_t n_real, int match, int mismatch, int gap, int rl) {
+    int build_mini(pwa_ctx* ctx, std::vector<PairDesc>& pd, uint32_t n_real, int match, int mismatch, int gap, int rl, int ln = 16) {
         mini = true;
+        mini_ln = ln;
         geom = PairGeom{rl, 1};
-        if (pd.empty() || pd.size() % 4 || pd.size() >= 0xffffffffull || n_real > pd.size() || n_real + 3 < pd.size())
+        const size_t ppw = (size_t)(64 / ln);   // pairs per wave: 4, or 1 (one pair per wave: 512- / 1024-row single stripes)
+        if (pd.empty() || pd.size() % ppw || pd.size() >= 0xffffffffull || n_real > pd.size() || n_real + ppw - 1 < pd.size())
             return fail(ctx, PWA_E_INVALID, "internal: mini-stripe task list");
         for (size_t q = 0; q < pd.size(); ++q) {
-            pd[q].first_task = (uint32_t)(q / 4);
+            pd[q].first_task = (uint32_t)(q / ppw);
             pd[q].first_stripe = (uint32_t)q;
             pd[q].n_stripes = 1;
             pd[q].row_stride = 0;
@@ -531,7 +534,7 @@ struct PairLaunch {
         G = PairParams{};
         G.pairs = static_cast<PairDesc*>(p_desc);
         G.n_pairs = n_real;
-        G.n_tasks = (uint32_t)(pd.size() / 4);
+        G.n_tasks = (uint32_t)(pd.size() / ppw);
         G.queue = static_cast<uint32_t*>(p_queue);
         G.best = static_cast<StripeBest*>(p_best);
         G.match = match;
@@ -547,8 +550,8 @@ struct PairLaunch {
     int launch(pwa_ctx* ctx, hipStream_t st, bool local, bool tb, int walk, hipEvent_t after_fill, bool sband = false) {
         HIPC(ctx, hipMemsetAsync(p_queue, 0, 16, st));
         if (mini) {
-            const pair_kernel_t fill = mini_fill_kernel_for(geom.rl, local, sband, gap0 && !sband && !local, tb);   // tb = false: no band at all
-            const pair_kernel_t walk_fn = mini_traceback_kernel_for(geom.rl, local, tb ? walk : (int)WALK_NONE);
+            const pair_kernel_t fill = mini_fill_kernel_for(geom.rl, local, sband, gap0 && !sband && !local, tb, mini_ln);   // tb = false: no band at all
+            const pair_kernel_t walk_fn = mini_traceback_kernel_for(geom.rl, local, tb ? walk : (int)WALK_NONE, mini_ln);
             if (!fill || !walk_fn || !perm || !keyed) return fail(ctx, PWA_E_INVALID, "internal: no mini-stripe kernel for this form");
             // Workgroups of four waves (one task each per round); `per_cu` of them per CU, enforced through the dynamic LDS request, so
             // that no CU gets more than its share whatever ran before (mini_fill.hip.h): with ceil(tasks / 4) workgroups for 256 CUs,
@@ -2135,16 +2138,27 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     const int k_match = gap0 ? match - 2 * gap : match, k_mismatch = gap0 ? mismatch - 2 * gap : mismatch, k_gap = gap0 ? 0 : gap;
     // the mini-stripe engine exists for keyed cells with table scoring; PWA_FORCE_RL / PWA_FORCE_W address the stripe engine
     const bool mini_ok = coded && keyed && ctx->knobs.tb_engine != 0 && !ctx->knobs.force_rl && !ctx->knobs.force_w;
-    auto class_of = [&](uint64_t n) -> TbClass {
+    // patterns of 257 .. 1024 rows: ONE wave per pair (mini-stripe kernels with 64 lanes per pair, RL = 8 | 16) instead of 4 - 8 pipelined
+    // stripes -- when the call has enough of them to occupy the chip that way (a few such pairs are faster spread over more waves)
+    uint64_t n_mid = 0;
+    for (uint64_t k = 0; k < n_pairs; ++k) {
+        const uint64_t n = slen(pair_a[k]);
+        n_mid += n > 256 && n <= 1024 && slen(pair_b[k]) > 0;
+    }
+    const bool wide_ok = mini_ok && (n_mid >= 256 || ctx->knobs.tb_engine == 2);
+    auto class_of = [&](uint64_t n) -> TbClass {   // (w of a mini class = its lanes per pair)
         if (mini_ok && n <= 256)
             for (const int rl : kMiniRL)
-                if (n <= (uint64_t)(16 * rl)) return TbClass{true, rl, 1};
+                if (n <= (uint64_t)(16 * rl)) return TbClass{true, rl, 16};
+        if (wide_ok && n <= 1024) return TbClass{true, n <= 384 ? 6 : n <= 512 ? 8 : n <= 768 ? 12 : 16, 64};
         const PairGeom g = choose_geom(ctx->knobs, n, keyed, true);
         return TbClass{false, g.rl, g.w};
     };
-    // band bytes of a pair: the stripe engine's own; the mini-stripe engine's for a text of m_task columns (its task's longest)
+    // band bytes of a pair: the stripe engine's own (also the one-pair-per-wave form's: a single stripe of 64 RL rows); the four-pair
+    // mini-stripe form's for a text of m_task columns (its task's longest)
     auto band_of = [&](const TbClass& c, uint64_t n, uint64_t m_task) -> uint64_t {
-        if (c.mini) return (uint64_t)mini_band_steps(m_task) * 16 * (uint64_t)c.rl;
+        if (c.mini && c.w == 16) return (uint64_t)mini_band_steps(m_task) * 16 * (uint64_t)c.rl;
+        if (c.mini) return (uint64_t)band_steps(m_task) * 64 * (uint64_t)c.rl;
         return ::tb_band_bytes(n, m_task, c.rl);
     };
 
@@ -2228,10 +2242,11 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
             const size_t np = L.q.size();
             L.bo.resize(np);
             if (L.cls.mini) {
+                const size_t ppw = (size_t)(64 / L.cls.w);
                 std::stable_sort(L.q.begin(), L.q.end(), [&](uint32_t x, uint32_t y) { return slen(pair_b[k0 + x]) > slen(pair_b[k0 + y]); });
                 L.mt.resize(np);
-                for (size_t p = 0; p < np; ++p) L.mt[p] = slen(pair_b[k0 + L.q[p / 4 * 4]]);   // the task's first pair has its longest text
-                L.n_dummy = (uint32_t)((4 - np % 4) % 4);
+                for (size_t p = 0; p < np; ++p) L.mt[p] = slen(pair_b[k0 + L.q[p / ppw * ppw]]);   // the task's first pair has its longest text
+                L.n_dummy = (uint32_t)((ppw - np % ppw) % ppw);
             }
             for (size_t p = 0; p < np; ++p) {
                 L.bo[p] = bo;
@@ -2329,12 +2344,12 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
             pl.perm = coded && keyed;
             pl.keyed = keyed;
             pl.gap0 = gap0;
-            int rc = L.cls.mini ? pl.build_mini(ctx, pd, (uint32_t)np, k_match, k_mismatch, k_gap, L.cls.rl)
+            int rc = L.cls.mini ? pl.build_mini(ctx, pd, (uint32_t)np, k_match, k_mismatch, k_gap, L.cls.rl, L.cls.w)
                                 : pl.build(ctx, pd, k_match, k_mismatch, k_gap, PairGeom{L.cls.rl, L.cls.w});
             if (rc != PWA_OK) return rc;
             pl.G.dash = dash_sym;
             mark("task list build + upload");
-            if (dbg) std::fprintf(stderr, "[pwa] fill launch %s RL=%d W=%d grid=%u pairs=%u tasks=%u rows=%llu\n", L.cls.mini ? "mini" : "stripes", L.cls.rl,
+            if (dbg) std::fprintf(stderr, "[pwa] fill launch %s RL=%d W|LN=%d grid=%u pairs=%u tasks=%u rows=%llu\n", L.cls.mini ? "mini" : "stripes", L.cls.rl,
                                   L.cls.w, pl.grid, pl.G.n_pairs, pl.G.n_tasks, (unsigned long long)pl.row_bytes);
             HIPC(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
             rc = pl.launch(ctx, ctx->stream, local, true, want_ops ? WALK_OPS : WALK_OVERLAP, ctx->ev[1], ctx->score_band);
@@ -2471,20 +2486,25 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     }
     const int64_t kd_match = ((int64_t)match - gap) * 4 + 2, kd_mismatch = ((int64_t)mismatch - gap) * 4 + 2;
     const bool coded = n_alpha <= 7 && kd_match <= 127 && kd_match >= -126 && kd_mismatch <= 127 && kd_mismatch >= -126 && !ctx->knobs.no_pair_table;
-    int mini_rl = 0;
-    if (coded && keyed && n <= 256 && ctx->knobs.tb_engine != 0 && !ctx->knobs.force_rl && !ctx->knobs.force_w)
-        for (const int rl : kMiniRL)
-            if (!mini_rl && n <= (uint64_t)(16 * rl)) mini_rl = rl;
-    const PairGeom geom = mini_rl ? PairGeom{mini_rl, 1} : choose_geom(ctx->knobs, n, keyed, true);
+    int mini_rl = 0, wide_rl = 0;   // wide: one pair per wave (PWA_TB_ENGINE=2 here: a single pair would normally take pipelined stripes)
+    if (coded && keyed && ctx->knobs.tb_engine != 0 && !ctx->knobs.force_rl && !ctx->knobs.force_w) {
+        if (n <= 256) {
+            for (const int rl : kMiniRL)
+                if (!mini_rl && n <= (uint64_t)(16 * rl)) mini_rl = rl;
+        } else if (n <= 1024 && ctx->knobs.tb_engine == 2) {
+            wide_rl = n <= 384 ? 6 : n <= 512 ? 8 : n <= 768 ? 12 : 16;
+        }
+    }
+    const PairGeom geom = mini_rl ? PairGeom{mini_rl, 1} : wide_rl ? PairGeom{wide_rl, 1} : choose_geom(ctx->knobs, n, keyed, true);
     const uint64_t kRL = (uint64_t)geom.rl;
-    const uint64_t band = mini_rl ? (uint64_t)mini_band_steps(m) * 16 * kRL : tb_band_bytes(n, m, geom.rl);
+    const uint64_t band = mini_rl ? (uint64_t)mini_band_steps(m) * 16 * kRL : tb_band_bytes(n, m, geom.rl);   // (wide: one 64 RL-row stripe)
     DevBuf d_pat, d_txt, d_band, d_sband, d_res;
     HIPC(ctx, d_pat.alloc(n + 64));
     HIPC(ctx, d_txt.alloc(m + 64));
     HIPC(ctx, d_band.alloc((mini_rl ? 4 : 1) * band + 32768));
     HIPC(ctx, d_sband.alloc((mini_rl ? 4 : 1) * band * sizeof(int32_t)));
     HIPC(ctx, d_res.alloc(sizeof(PairResult)));
-    if (mini_rl) {
+    if (mini_rl || wide_rl) {
         std::vector<uint8_t> cp(n), ct(m);
         for (uint64_t o = 0; o < n; ++o) cp[o] = code_of[pattern[o]];
         for (uint64_t o = 0; o < m; ++o) ct[o] = code_of[text[o]];
@@ -2517,6 +2537,9 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
         }
         pl.perm = true;
         rc = pl.build_mini(ctx, pd, 1, match, mismatch, gap, mini_rl);
+    } else if (wide_rl) {
+        pl.perm = true;
+        rc = pl.build_mini(ctx, pd, 1, match, mismatch, gap, wide_rl, 64);
     } else {
         rc = pl.build(ctx, pd, match, mismatch, gap, geom);
     }
@@ -2534,15 +2557,16 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     static const char kCodeNW[4] = {'u', 'l', 'd', 'd'}, kCodeSW[4] = {'l', 'u', 'd', '0'};   // hw2.cpp:145-153 / 214-222
     const char* const kCode = local ? kCodeSW : kCodeNW;
     const uint64_t T = band_steps(m);
-    const uint64_t PA = kRL >= 16 ? 16 : (kRL >= 8 ? 8 : 4), PB = kRL - PA;   // BandGeo<16, RL>
+    const uint64_t PA = kRL >= 16 ? 16 : (kRL >= 8 ? 8 : 4), PB = kRL - PA;   // BandGeo<LN, RL> of the mini-stripe kernels
+    const uint64_t LN = mini_rl ? 16 : 64, Q4 = kRL & ~(uint64_t)3, W4 = kRL & 3;
     for (uint64_t i = 1; i <= n; ++i) {
         const uint64_t q = i - 1;
         for (uint64_t j = 1; j <= m; ++j) {
             uint64_t idx, sidx;   // skewed bands -> row-major matrix
-            if (mini_rl) {
+            if (mini_rl || wide_rl) {
                 const uint64_t k = q / kRL, r = q % kRL, t = j - 1 + k;
-                idx = t * 16 * kRL + (r < PA ? k * PA + r : 16 * PA + k * PB + (r - PA));
-                sidx = (t * 16 + k) * kRL + r;
+                idx = t * LN * kRL + (r < PA ? k * PA + r : LN * PA + k * PB + (r - PA));
+                sidx = t * LN * kRL + (r < Q4 ? (r >> 2) * (LN * 4) + k * 4 + (r & 3) : Q4 * LN + k * W4 + (r & 3));   // BandGeo::sband_off
             } else {
                 const uint64_t st = q / (64 * kRL), k = (q % (64 * kRL)) / kRL, r = q % kRL;
                 idx = sidx = ((st * T + (j - 1 + k)) * 64 + k) * kRL + r;

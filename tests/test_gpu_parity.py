@@ -664,7 +664,7 @@ def test_device_score_vector_in_caller_memory(sctx):
         b.close()
 
 
-@pytest.mark.parametrize("engine", ["mini", "stripes"])
+@pytest.mark.parametrize("engine", ["mini", "stripes", "wide"])
 def test_whole_matrices_match_reference_matrices(engine):
     """Every cell of the int32 score band and of the traceback band == the reference's `dp` and `traceback`
     matrices (hw2.cpp:119-156 / 193-231), incl. row/column 0, several stripes, all scorings.  "mini": patterns of up to 256 rows
@@ -675,7 +675,10 @@ def test_whole_matrices_match_reference_matrices(engine):
     cases = [(1, 1), (3, 70), (70, 3), (255, 300), (256, 64), (257, 65), (600, 777), (1100, 90)]
     if engine == "mini":
         cases += [(64, 100), (65, 31), (96, 200), (97, 16), (128, 129), (129, 15), (150, 333), (160, 47), (161, 48), (192, 17), (193, 250), (16, 1), (17, 500)]
-    with switched_context(**({"PWA_TB_ENGINE": "0"} if engine == "stripes" else {})) as c:
+    if engine == "wide":   # PWA_TB_ENGINE=2: one pair per wave for 257 .. 1024 rows (RL = 8 | 16), as batches of such patterns run
+        cases = [(257, 65), (300, 700), (384, 50), (385, 49), (511, 64), (512, 100), (513, 40), (768, 20), (769, 21), (1023, 63), (1024, 33),
+                 (1000, 1100), (1025, 70)]   # RL = 6 / 8 / 12 / 16 classes at both ends; 1025: stripe engine
+    with switched_context(**({"PWA_TB_ENGINE": "0"} if engine == "stripes" else {"PWA_TB_ENGINE": "2"} if engine == "wide" else {})) as c:
         for (n, m) in cases:
             p = bytes(rng.choice(b"ACGT") for _ in range(n))
             t = bytes(rng.choice(b"ACGT") for _ in range(m))
@@ -942,7 +945,8 @@ def test_one_shot_scores_are_pipelined_over_runs(ctx):
 @pytest.mark.parametrize("engine,n_class", [("stripes", (1, 63, 64)), ("stripes", (65, 127, 128)), ("stripes", (129, 200, 256)),
                                             ("stripes", (257, 300, 511, 512, 513)), ("stripes", (700, 1025, 1100, 1537)),
                                             ("mini", (1, 15, 16, 17, 63, 64)), ("mini", (65, 95, 96, 97, 127, 128)),
-                                            ("mini", (129, 150, 159, 160, 161)), ("mini", (191, 192, 193, 255, 256, 257))])
+                                            ("mini", (129, 150, 159, 160, 161)), ("mini", (191, 192, 193, 255, 256, 257)),
+                                            ("wide", (257, 300, 384, 385, 511, 512, 513)), ("wide", (700, 768, 769, 1023, 1024, 1025))])
 def test_pair_engine_shapes_around_every_boundary(engine, n_class):
     """The written-out fill chunks (r02): pattern lengths around stripe / workgroup boundaries x text lengths around hand-off chunks
     (16 steps), the lane ramp (63 steps) and the LDS ring (512 columns), for both modes, table and compare scoring, gap-shifted and
@@ -965,6 +969,8 @@ def test_pair_engine_shapes_around_every_boundary(engine, n_class):
     for env, band in variants:
         if engine == "stripes":
             env = dict(env, PWA_TB_ENGINE="0")
+        if engine == "wide":   # one pair per wave for 257 .. 1024 rows, however few (the longest of each class: the stripe engine)
+            env = dict(env, PWA_TB_ENGINE="2")
         with switched_context(**env) as c:
             c.set_score_band(band)
             for mode in ("nw", "sw"):
@@ -1004,6 +1010,33 @@ def test_every_pair_gets_its_own_geometry(ctx):
         scores, ovl = ctx.overlaps(mode, seqs, pa, pb, 1, -1, -1)
         for k, r in enumerate(res):
             want = O.align(mode, seqs[pa[k]], seqs[pb[k]], 1, -1, -1, compact=True)
+            assert (r["score"], r["ops"], tuple(r["end"]), tuple(r["start"])) == \
+                (want["score"], want["ops"], tuple(want["end"]), tuple(want["start"])), (mode, k, len(seqs[pa[k]]), len(seqs[pb[k]]))
+            assert (scores[k], ovl[k]) == (want["score"], want["overlap"]), (mode, k)
+
+
+def test_batches_of_mid_sized_patterns_run_one_pair_per_wave(ctx):
+    """r03: 300 pairs with patterns of 257 .. 1024 rows in one call -- enough of them for the one-pair-per-wave form of the mini-stripe
+    kernels (64 lanes x 8 | 16 rows, a single stripe per pair) -- next to a few short and a few longer ones: op lists, cells, scores and
+    overlaps against the oracle."""
+    rng = random.Random(1024)
+    seqs, pa, pb = [], [], []
+    for k in range(300):
+        n = rng.choice([257, 300, 400, 511, 512, 513, 700, 1000, 1023, 1024])
+        p = O.gen(60, 0, k, n)
+        t = (_mutate(rng, p, 0.12) if k % 3 else O.gen(60, 1, k, rng.randint(50, 400)))[:rng.randint(40, 1100)]
+        seqs.extend([p, t])
+        pa.append(len(seqs) - 2)
+        pb.append(len(seqs) - 1)
+    for n in (100, 1025, 2000):
+        seqs.extend([O.gen(61, 0, n, n), O.gen(61, 1, n, 300)])
+        pa.append(len(seqs) - 2)
+        pb.append(len(seqs) - 1)
+    for mode in ("nw", "sw"):
+        res = ctx.align_batch(mode, seqs, pa, pb, 2, -3, -5)
+        scores, ovl = ctx.overlaps(mode, seqs, pa, pb, 2, -3, -5)
+        for k, r in enumerate(res):
+            want = O.align(mode, seqs[pa[k]], seqs[pb[k]], 2, -3, -5, compact=True)
             assert (r["score"], r["ops"], tuple(r["end"]), tuple(r["start"])) == \
                 (want["score"], want["ops"], tuple(want["end"]), tuple(want["start"])), (mode, k, len(seqs[pa[k]]), len(seqs[pb[k]]))
             assert (scores[k], ovl[k]) == (want["score"], want["overlap"]), (mode, k)
