@@ -38,4 +38,36 @@ for mode in ("nw", "sw"):
     for it in range(reps):
         assert [key(r) for r in ctx.align_batch(mode, seqs, pa, pb, 1, -1, -1)] == first, (mode, it)
     print("batch %s: %d identical runs, %.1f s" % (mode, reps + 1, time.time() - t0), flush=True)
+# r03: the one-pair-per-wave form (>= 256 pairs of 257 .. 1024 rows in one call), the -g selection walk, and a split scores pass
+seqs, pa, pb = [], [], []
+for k in range(400):
+    n, m = rng.choice([300, 500, 700, 1000]), rng.choice([400, 900, 2500])
+    seqs += [gen(8, 0, k, n), gen(8, 1, k, m)]; pa.append(2 * k); pb.append(2 * k + 1)
+for mode in ("nw", "sw"):
+    first = [key(r) for r in ctx.align_batch(mode, seqs, pa, pb, 1, -1, -1)]
+    first_ov = ctx.overlaps(mode, seqs, pa, pb, 1, -1, -1)
+    for k in range(0, 400, 41):
+        w = O.align(mode, seqs[pa[k]], seqs[pb[k]], 1, -1, -1, compact=True)
+        assert first[k] == (w["score"], hashlib.sha256(w["ops"]).hexdigest(), tuple(w["end"]), tuple(w["start"]))
+        assert (first_ov[0][k], first_ov[1][k]) == (w["score"], w["overlap"])
+    for it in range(reps):
+        assert [key(r) for r in ctx.align_batch(mode, seqs, pa, pb, 1, -1, -1)] == first, (mode, it)
+        assert ctx.overlaps(mode, seqs, pa, pb, 1, -1, -1) == first_ov, (mode, it)
+    print("mid-sized batch %s (one pair per wave) + overlaps: %d identical runs, %.1f s" % (mode, reps + 1, time.time() - t0), flush=True)
+seqs = [gen(9, 0, k, rng.choice([40, 100, 150, 250])) for k in range(3000)] + [gen(9, 1, k, rng.randint(200, 900)) for k in range(3000)]
+seqs += [gen(9, 0, 5000, 4000), gen(9, 1, 5000, 6000)]
+pa = list(range(3000)) + [6000]
+pb = [3000 + k for k in range(3000)] + [6001]
+for mode in ("nw", "sw"):
+    b = ctx.batch(mode, seqs, pa, pb, 1, -1, -1)
+    b.run()
+    first = b.fetch()
+    kern = b.info()["kernel"]
+    for k in list(range(0, 3000, 97)) + [3000]:
+        assert first[k] == O.score(mode, seqs[pa[k]], seqs[pb[k]], 1, -1, -1)[0], (mode, k)
+    for it in range(reps * 3):
+        b.run()
+        assert b.fetch() == first, (mode, it)
+    b.close()
+    print("split scores pass %s [%s]: %d identical runs, %.1f s" % (mode, kern, reps * 3 + 1, time.time() - t0), flush=True)
 print("soak ok")
