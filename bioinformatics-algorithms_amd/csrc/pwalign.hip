@@ -644,7 +644,7 @@ struct pwa_batch {
     std::vector<std::unique_ptr<PairLaunch>> mini;   // engine 3: mini-stripe launches without a band, one per row class (short patterns routed off the strips)
     DevBuf pair_res;
     uint64_t n_live = 0;            // pairs that reach a kernel (n > 0 and m > 0)
-    std::vector<uint32_t> live_idx; // engine 2: pair index of descriptor k
+    std::vector<uint32_t> live_idx; // pairs off the strips: pair index of result slot q (stripe engine's pairs first, then the mini launches')
     std::vector<int32_t> host_scores;   // trivial pairs resolved on the host
     std::vector<uint32_t> host_end_i, host_end_j;
     std::string kernel_name;
@@ -955,11 +955,14 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         }
     arena_bytes += 512;   // slack: strips and text words are over-read, never over-used
     if (arena_bytes >= 0xffffffffull) return fail(ctx, PWA_E_CAPACITY, "sequence arena exceeds 4 GiB");
-    const bool arena_coded = b->use_strips && score_path == SC_PERM;
+    // (a scores pass that wants end cells runs wholly off the strips: its arena is coded whenever the alphabet allows, for the mini-stripe
+    // kernels -- the stripe engine's compare form is the same on codes, a pattern-only symbol is code 7 and equals no text code)
+    const bool code_for_end_cells = b->want_end && !affine && !nwdist && n_alpha <= 7 && ctx->knobs.tb_engine != 0;
+    const bool arena_coded = (b->use_strips && score_path == SC_PERM) || code_for_end_cells;
     // Short patterns that a scores pass routes away from the strips run on the mini-stripe engine WITHOUT a band (mini_fill.hip.h,
     // BAND = false: four pairs per wave) where it applies: coded arena, keyed cells in range, table constants in a byte.
     bool mini_scores = false, mini_gap0 = false;
-    if (arena_coded && !affine && !nwdist && !b->want_end && ctx->knobs.tb_engine != 0 && tb_range_ok(max_n + max_m, match, mismatch, gap)) {
+    if (arena_coded && !affine && !nwdist && ctx->knobs.tb_engine != 0 && tb_range_ok(max_n + max_m, match, mismatch, gap)) {
         const int64_t kdm = ((int64_t)match - gap) * 4 + 2, kdx = ((int64_t)mismatch - gap) * 4 + 2;
         mini_scores = kdm <= 127 && kdm >= -126 && kdx <= 127 && kdx >= -126;
         if (mini_scores && !local) {
@@ -1425,6 +1428,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             pd.reserve(lst.size() + 3);
             for (const uint32_t k : lst) {
                 PairDesc d = describe(k, q_next++);
+                b->live_idx.push_back(k);
                 d.score_bias = mini_gap0 ? wrap_mul((int64_t)(slen(pair_a[k]) + slen(pair_b[k])), gap) : 0;
                 pd.push_back(d);
                 b->padded_cells += (uint64_t)(16 * rl) * slen(pair_b[k]);
@@ -1820,7 +1824,7 @@ int pwa_batch_info(const pwa_batch* b, uint64_t* cells, uint64_t* padded_cells, 
     if (cells) *cells = b->cells;
     if (padded_cells) *padded_cells = b->padded_cells;
     if (n_tasks) {
-        *n_tasks = (b->use_strips ? b->bp.n_tasks : 0) + (b->use_pairs ? b->live_idx.size() : 0);
+        *n_tasks = (b->use_strips ? b->bp.n_tasks : 0) + (b->use_pairs ? (uint64_t)b->pl.G.n_pairs : 0);
         for (const auto& ml : b->mini) *n_tasks += ml->G.n_tasks;
     }
     if (kernel_name) *kernel_name = b->kernel_name.c_str();
@@ -1851,7 +1855,7 @@ int pwa_batch_fetch(pwa_batch* b, int32_t* score_out, uint32_t* end_i_out, uint3
         }
         return PWA_OK;
     }
-    std::vector<PairResult> res(b->n_live);   // end cells asked for: every live pair ran on the stripe engine
+    std::vector<PairResult> res(b->n_live);   // end cells asked for: every live pair ran off the strips (stripe or mini-stripe engine)
     HIPC(ctx, hipMemcpy(res.data(), b->pair_res.p, b->n_live * sizeof(PairResult), hipMemcpyDeviceToHost));
     std::memcpy(score_out, b->host_scores.data(), b->n_pairs * sizeof(int32_t));
     if (b->want_end) {

@@ -28,7 +28,7 @@
  *                      of long patterns, scores with end cells, and -- by estimated cost -- the scores of pairs that would leave the
  *                      strip engine's waves under-filled (a few long pairs);
  *   mini-stripe engine 16 lanes per pair, four pairs per wave (mini_fill.hip.h): traceback fills of patterns of up to 256 rows, and --
- *                      without a band -- the scores of such pairs when a scores pass routes them off the strips.
+ *                      without a band -- the scores of such pairs when a scores pass routes them off the strips or asks for end cells.
  *   pwa_align_batch / pwa_overlaps pick the band geometry pair by pair; pwa_scores / pwa_batch_create split a list between the three
  *   engines by estimated cost.
  *

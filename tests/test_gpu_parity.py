@@ -246,6 +246,33 @@ def test_scores_end_cells_match_oracle(ctx):
                 assert (s[k], ei[k], ej[k]) == tuple(w), (mode, sc, k)
 
 
+@pytest.mark.parametrize("engine", ["auto", "stripes"])
+def test_scores_end_cells_with_ties_on_both_engines(engine):
+    """End cells of a scores pass: short patterns over a coded alphabet take the band-less mini-stripe kernels, everything else (and
+    everything under PWA_TB_ENGINE=0) the stripe engine.  Two-letter sequences put the maximum in many cells: the first one in
+    row-major order is the answer (hw2.cpp:225-229); a pattern-only symbol ('N') equals no text symbol on either engine."""
+    rng = random.Random(4242)
+    pats = [bytes(rng.choice(b"AC") for _ in range(n)) for n in (1, 2, 15, 16, 17, 63, 64, 65, 100, 150, 160, 161, 255, 256, 257, 300)]
+    pats += [bytes(rng.choice(b"ACN") for _ in range(150)), b"A" * 150, b"AC" * 75]
+    txts = [bytes(rng.choice(b"AC") for _ in range(m)) for m in (1, 5, 15, 16, 17, 31, 32, 33, 200, 1000, 1003)] + [b"A" * 333, b"CA" * 170]
+    seqs = pats + txts
+    pa = [i for i in range(len(pats)) for _ in txts]
+    pb = [len(pats) + j for _ in pats for j in range(len(txts))]
+    with switched_context(**({"PWA_TB_ENGINE": "0"} if engine == "stripes" else {})) as c:
+        for sc in [(1, -1, -1), (2, -3, -5), (1, 0, 0), (3, 1, -2)]:
+            for mode in ("nw", "sw"):
+                b = c.batch(mode, seqs, pa, pb, *sc, want_end=True)
+                try:
+                    assert ("mini_fill_kernel" in b.info()["kernel"]) == (engine == "auto"), b.info()["kernel"]
+                    b.run()
+                    s, ei, ej = b.fetch()
+                finally:
+                    b.close()
+                for k in range(len(pa)):
+                    w = O.score(mode, seqs[pa[k]], seqs[pb[k]], *sc)
+                    assert (s[k], ei[k], ej[k]) == tuple(w), (mode, sc, k, len(seqs[pa[k]]), len(seqs[pb[k]]))
+
+
 def test_scores_many_strips_and_long_texts(sctx):
     ctx = sctx
     """patterns spanning several register strips, texts with every length residue mod 4."""
