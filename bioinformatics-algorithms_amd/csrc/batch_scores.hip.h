@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256, strip_waves_per_simd(R, MODE)) void batch_scor
     // (H[i][j] = i*g), so a lane's real matrix simply starts p = M - m columns late, every lane ends in the last
     // block, and H[n][m] = G'[n][M] + g(n + M).  Only row 0 differs per lane: H[0][j] = g * max(j - p, 0).
     static_assert(!LANES || MODE == BM_SWS || MODE == BM_SW || MODE == BM_NWG, "per-lane texts: SW forms and gap-shifted NW");
+    static_assert(R % 4 == 0, "a strip is whole quads of rows (one packed symbol word each)");
     constexpr int Q = R / 4;
     const int lane = threadIdx.x & 63;
     int32_t* const hand = P.hand + ((size_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * P.hand_stride;
