@@ -245,6 +245,28 @@ void counting_sort(std::vector<uint32_t>& idx, std::vector<uint32_t>& tmp, size_
     idx.swap(tmp);
 }
 
+// idx by DESCENDING length, stable (equal lengths keep their order): linear passes instead of std::stable_sort's n log n compares
+// through two indirections ([cpu] 16 384 pairs of random lengths: 0.95 ms for the merge sort)
+template <class LenFn>
+void sort_by_length_desc(std::vector<uint32_t>& idx, LenFn len_of) {
+    if (idx.size() < 2) return;
+    uint64_t lmin = ~0ull, lmax = 0;
+    for (const uint32_t v : idx) {
+        const uint64_t l = len_of(v);
+        lmin = std::min(lmin, l);
+        lmax = std::max(lmax, l);
+    }
+    if (lmin == lmax) return;
+    if (lmax - lmin <= 4 * (uint64_t)idx.size() + 65536) {
+        std::vector<uint32_t> tmp;
+        counting_sort(idx, tmp, (size_t)(lmax - lmin + 1), [&](uint32_t v) { return (size_t)(lmax - len_of(v)); });
+    } else {
+        std::vector<uint64_t> key(idx.size());
+        for (size_t o = 0; o < idx.size(); ++o) key[o] = lmax - len_of(idx[o]);
+        radix_sort_by_key(key, idx);
+    }
+}
+
 // Runs fn(first_seq, last_seq, thread) over the sequences, split into byte-balanced contiguous ranges, on up to
 // 16 host threads (one per >= 8 MiB): the host passes over the input (alphabet scan, symbol coding into the
 // arena) are memory-bound loops that otherwise dominate the call for inputs of hundreds of MB.
@@ -1410,7 +1432,13 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             pd.reserve(plist.size());
             uint64_t pe_max_n = 0;
             for (const uint32_t k : plist) pe_max_n = std::max(pe_max_n, slen(pair_a[k]));
-            const PairGeom geom = choose_geom(ctx->knobs, pe_max_n);
+            PairGeom geom = choose_geom(ctx->knobs, pe_max_n);
+            {   // RL = 2 buys a pair more waves in flight -- which a list that fills the chip anyway does not need: [gpu, r03] SW scores of
+                // 10k x 10k pairs, RL = 2 / RL = 4: 8 pairs 1.73 / 1.79 ms, 64 pairs 5.35 / 4.93 ms, 256 pairs 17.3 / 12.8 ms
+                uint64_t stripes2 = 0;
+                for (const uint32_t k : plist) stripes2 += (slen(pair_a[k]) + 127) / 128;
+                if (geom.rl == 2 && geom.w == 4 && !ctx->knobs.force_rl && stripes2 >= 2048) geom.rl = 4;
+            }
             for (const uint32_t k : plist) {
                 pd.push_back(describe(k, q_next++));
                 b->padded_cells += (slen(pair_a[k]) + 64 * geom.rl - 1) / (64 * geom.rl) * (64 * geom.rl) * slen(pair_b[k]);
@@ -1423,7 +1451,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         for (auto& cls : mini_lists) {
             const int rl = cls.first;
             std::vector<uint32_t>& lst = cls.second;
-            std::stable_sort(lst.begin(), lst.end(), [&](uint32_t x, uint32_t y) { return slen(pair_b[x]) > slen(pair_b[y]); });   // a wave's four texts about equally long
+            sort_by_length_desc(lst, [&](uint32_t x) { return slen(pair_b[x]); });   // a wave's four texts about equally long
             std::vector<PairDesc> pd;
             pd.reserve(lst.size() + 3);
             for (const uint32_t k : lst) {
@@ -2116,6 +2144,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     // overlapLongestExactMatch (hw2.cpp:269) does not count a column whose symbols are '-' -- also when the '-' is part
     // of the input sequence itself: the walk needs the arena's value for that byte
     const int32_t dash_sym = !dash_seen ? 0x100 : (coded ? (int32_t)code_of[(unsigned char)'-'] : (int32_t)'-');
+    mark("validate + alphabet scan");
     DevBuf arena_own;
     void* p_arena = nullptr;
     {
@@ -2150,12 +2179,23 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         n_mid += n > 256 && n <= 1024 && slen(pair_b[k]) > 0;
     }
     const bool wide_ok = mini_ok && (n_mid >= 256 || ctx->knobs.tb_engine == 2);
+    // the stripe engine's pairs: RL = 2 gives ONE pair more waves in flight (10 % at 10k x 10k), but a list whose stripes fill the chip anyway
+    // runs faster on fewer, taller ones -- [gpu, r03] fills at RL = 2 / RL = 4, NW: 16 pairs 10k x 10k 1.90 / 1.22 ms, 64 pairs 4.12 / 3.33,
+    // 256 pairs 12.8 / 8.7, 512 pairs 2000 x 2000 1.07 / 0.75, 32 pairs 30k x 30k 18.0 / 12.4 (profiles/r03_align_shapes.txt)
+    uint64_t stripes2 = 0;
+    for (uint64_t k = 0; k < n_pairs; ++k) {
+        const uint64_t n = slen(pair_a[k]);
+        if (!slen(pair_b[k]) || n > 0x7fffffc0ull || (mini_ok && n <= 256) || (wide_ok && n <= 1024)) continue;
+        stripes2 += (n + 127) / 128;
+    }
+    const bool tall_stripes = stripes2 >= 1024 && !ctx->knobs.force_rl;
     auto class_of = [&](uint64_t n) -> TbClass {   // (w of a mini class = its lanes per pair)
         if (mini_ok && n <= 256)
             for (const int rl : kMiniRL)
                 if (n <= (uint64_t)(16 * rl)) return TbClass{true, rl, 16};
         if (wide_ok && n <= 1024) return TbClass{true, n <= 384 ? 6 : n <= 512 ? 8 : n <= 768 ? 12 : 16, 64};
-        const PairGeom g = choose_geom(ctx->knobs, n, keyed, true);
+        PairGeom g = choose_geom(ctx->knobs, n, keyed, true);
+        if (tall_stripes && g.rl == 2 && g.w == 4) g.rl = 4;
         return TbClass{false, g.rl, g.w};
     };
     // band bytes of a pair: the stripe engine's own (also the one-pair-per-wave form's: a single stripe of 64 RL rows); the four-pair
@@ -2199,6 +2239,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
             if (n_ranges > 1) chunk_target = std::min<uint64_t>(cap, total / n_ranges + total / live + (1ull << 20));   // equal shares (+ one average pair)
         }
     }
+    mark("plan: memory + range size");
     struct Launch {                    // the pairs of one class inside one range
         TbClass cls;
         std::vector<uint32_t> q;       // pair index inside the range, in launch order (mini: longest text first)
@@ -2247,7 +2288,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
             L.bo.resize(np);
             if (L.cls.mini) {
                 const size_t ppw = (size_t)(64 / L.cls.w);
-                std::stable_sort(L.q.begin(), L.q.end(), [&](uint32_t x, uint32_t y) { return slen(pair_b[k0 + x]) > slen(pair_b[k0 + y]); });
+                sort_by_length_desc(L.q, [&](uint32_t x) { return slen(pair_b[k0 + x]); });
                 L.mt.resize(np);
                 for (size_t p = 0; p < np; ++p) L.mt[p] = slen(pair_b[k0 + L.q[p / ppw * ppw]]);   // the task's first pair has its longest text
                 L.n_dummy = (uint32_t)((ppw - np % ppw) % ppw);
@@ -2278,6 +2319,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         ranges.push_back(std::move(rg));
         k0 = k1;
     }
+    mark("plan: ranges + launches");
     DevBuf d_band, d_sband, d_ops_own, d_res_own;
     void *p_band = nullptr, *p_sband = nullptr, *p_ops = nullptr, *p_res = nullptr;
     if (!ranges.empty()) {

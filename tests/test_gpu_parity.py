@@ -273,6 +273,29 @@ def test_scores_end_cells_with_ties_on_both_engines(engine):
                     assert (s[k], ei[k], ej[k]) == tuple(w), (mode, sc, k, len(seqs[pa[k]]), len(seqs[pb[k]]))
 
 
+def test_scores_end_cells_of_a_chip_filling_list_of_long_patterns(ctx):
+    """Enough multi-stripe pairs to fill the chip: the stripe engine takes them at RL = 4 (fewer, taller stripes) instead of the
+    RL = 2 it gives a handful of long pairs; same scores and end cells (oracle)."""
+    rng = random.Random(99)
+    alphabet = bytes(range(65, 91))
+    pats = [bytes(rng.choice(alphabet[:3]) for _ in range(rng.randint(1900, 2100))) for _ in range(300)]
+    txts = [bytes(rng.choice(alphabet[:3]) for _ in range(rng.randint(250, 330))) for _ in range(300)]
+    txts[0] = alphabet * 12   # > 7 text symbols: no coded arena, no mini-stripe kernels
+    seqs = pats + txts
+    pa = list(range(300))
+    pb = [300 + i for i in range(300)]
+    for mode in ("sw", "nw"):
+        b = ctx.batch(mode, seqs, pa, pb, 2, -3, -2, want_end=True)
+        try:
+            assert "pair_fill_kernel<RL=4" in b.info()["kernel"], b.info()["kernel"]
+            b.run()
+            s, ei, ej = b.fetch()
+        finally:
+            b.close()
+        for k in range(300):
+            assert (s[k], ei[k], ej[k]) == tuple(O.score(mode, seqs[pa[k]], seqs[pb[k]], 2, -3, -2)), (mode, k)
+
+
 def test_scores_many_strips_and_long_texts(sctx):
     ctx = sctx
     """patterns spanning several register strips, texts with every length residue mod 4."""
@@ -1057,6 +1080,33 @@ def test_batches_of_mid_sized_patterns_run_one_pair_per_wave(ctx):
         pb.append(len(seqs) - 1)
     for n in (100, 1025, 2000):
         seqs.extend([O.gen(61, 0, n, n), O.gen(61, 1, n, 300)])
+        pa.append(len(seqs) - 2)
+        pb.append(len(seqs) - 1)
+    for mode in ("nw", "sw"):
+        res = ctx.align_batch(mode, seqs, pa, pb, 2, -3, -5)
+        scores, ovl = ctx.overlaps(mode, seqs, pa, pb, 2, -3, -5)
+        for k, r in enumerate(res):
+            want = O.align(mode, seqs[pa[k]], seqs[pb[k]], 2, -3, -5, compact=True)
+            assert (r["score"], r["ops"], tuple(r["end"]), tuple(r["start"])) == \
+                (want["score"], want["ops"], tuple(want["end"]), tuple(want["start"])), (mode, k, len(seqs[pa[k]]), len(seqs[pb[k]]))
+            assert (scores[k], ovl[k]) == (want["score"], want["overlap"]), (mode, k)
+
+
+def test_lists_of_long_patterns_take_taller_stripes(ctx):
+    """r03: a list whose multi-stripe pairs fill the chip by themselves runs the stripe engine at RL = 4 (one pair alone: RL = 2, more
+    waves in flight).  120 pairs with patterns of 1100 .. 3500 rows (a mutated copy of the pattern's head as text, so that the path
+    crosses stripes), a short and a very short one next to them: op lists, cells, scores and overlaps against the oracle."""
+    rng = random.Random(3500)
+    seqs, pa, pb = [], [], []
+    for k in range(120):   # >= 1080 stripes of 128 rows
+        n = rng.choice([1100, 2047, 2048, 2049, 3000, 3500])
+        p = O.gen(62, 0, k, n)
+        t = _mutate(rng, p, 0.1)[:rng.randint(200, 600)] if k % 4 else O.gen(62, 1, k, 300)
+        seqs.extend([p, t])
+        pa.append(len(seqs) - 2)
+        pb.append(len(seqs) - 1)
+    for n in (5, 150):
+        seqs.extend([O.gen(63, 0, n, n), O.gen(63, 1, n, 200)])
         pa.append(len(seqs) - 2)
         pb.append(len(seqs) - 1)
     for mode in ("nw", "sw"):
