@@ -808,10 +808,19 @@ struct BandGeo {
     }
 };
 
+#ifndef PWA_WALK_NARROW
+#define PWA_WALK_NARROW 1   // (0: experiment builds that fetch whole steps)
+#endif
+#ifndef PWA_WALK_WIN_WIDE_DIV
+#define PWA_WALK_WIN_WIDE_DIV 1   // (experiment builds: 2 halves the window of the one-pair-per-wave classes)
+#endif
 template <int RL, bool LOCAL, int WALK, int LN = 64>
 __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) {
     typedef BandGeo<LN, RL> Geo;
-    constexpr int WIN = LN * RL <= 256 ? 64 : (LN * RL <= 512 ? 32 : 16);   // steps per LDS window: 64, or the power of two that keeps a window <= 16 KiB
+    // steps per LDS window.  Stripe engine (LN = 64, RL = 2 | 4: few, long walks): 64 steps, <= 16 KiB.  Mini-stripe classes (many short
+    // walks, LDS decides how many run per CU): 32 steps -- [gpu, r03] 65 536 walks over 150 x 2000 bands 4.7 -> 3.05 ms, the `g` batch
+    // 0.362 -> 0.277 ms; 64 walks over 10k x 10k bands prefer the long window (0.48 against 0.585 ms)
+    constexpr int WIN = LN == 16 ? 32 : (LN * RL <= 256 ? 64 : (LN * RL <= 512 ? 32 : 16) / PWA_WALK_WIN_WIDE_DIV);
     static_assert((WIN & (WIN - 1)) == 0 && WIN * LN * RL <= 16384 && (WIN * LN * RL) % 1024 == 0, "window steps");
     constexpr int STEP_BYTES = LN * RL;
     constexpr int WB = WIN * STEP_BYTES;           // bytes per window (16 KiB for RL = 4)
@@ -859,8 +868,50 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
     if (WALK == WALK_NONE) return;
     // LDS-DMA of window w of stripe s into buffer `buf`: 1 KiB per instruction.  A window may run past
     // the end of its stripe or of the band; the host pads the band allocation by one window.
-    auto issue = [&](int buf, int s, int w) {
+    // NARROW (the one-pair-per-wave classes, LN = 64 and RL >= 6: a band step is 384 .. 1024 bytes wide): only the band lanes lo .. hi of
+    // every step are fetched -- a DMA lane whose 16 bytes hold none of them fetches a dummy line instead, the others land where they
+    // always did, so the LDS layout does not change.  The walk only ever needs the lanes at and a few below its anchor's (rows only decrease); without the
+    // mask a walk reads its pair's whole band again, and a batch of square-ish pairs spent as long in its walks as in its fills
+    // ([gpu, r03] 8192 pairs 1000 x 1000: fills 1.7 ms, walks 1.65 ms = 9 GB at 5.4 TB/s).
+    constexpr bool NARROW = LN == 64 && RL >= 6 && PWA_WALK_NARROW;
+    constexpr int DW = RL >= 12 ? 4 : 6;   // band lanes below the anchor's that a staged window holds (the prefetched one: twice that)
+    auto issue = [&](int buf, int s, int w, int lo, int hi) {
+        buf = __builtin_amdgcn_readfirstlane(buf);   // (wave-uniform by construction; the DMA's LDS base travels in M0)
         const size_t off0 = ((size_t)s * T + (size_t)w * WIN) * STEP_BYTES;
+        auto holds = [&](int byte_off) -> bool {   // do the 16 bytes at byte_off of the window hold a lane of lo .. hi?
+            if constexpr (!NARROW) return true;
+            const int bs = (int)((unsigned)byte_off % (unsigned)STEP_BYTES);
+            int l0, l1;
+            if (bs < LN * Geo::PA) {
+                l0 = bs / Geo::PA;
+                l1 = (bs + 15) / Geo::PA;
+            } else {
+                constexpr int PBd = Geo::PB ? Geo::PB : 1;
+                l0 = (bs - LN * Geo::PA) / PBd;
+                l1 = (bs - LN * Geo::PA + 15) / PBd;
+            }
+            return l1 >= lo && l0 <= hi;
+        };
+        if constexpr (NARROW) {
+            // (no branch around the DMA -- its LDS base travels in M0: a masked-out lane loads the first 16 bytes of its instruction's KiB
+            // instead, one cached line for all of them, into its own LDS slot, which no read touches: every read checks the lane against
+            // klo.)  Which lanes of an instruction hold lanes lo .. hi repeats every NPH instructions: NPH KiB are whole steps.
+            constexpr int NPH = (1024 % STEP_BYTES == 0 || STEP_BYTES % 1024 == 0) ? 1 : 3;
+            static_assert((NPH * 1024) % STEP_BYTES == 0 || STEP_BYTES % 1024 == 0, "the mask pattern's period");
+            uint32_t voff[NPH];
+#pragma unroll
+            for (int ph = 0; ph < NPH; ++ph) voff[ph] = holds(ph * 1024 + lane * 16) ? (uint32_t)lane * 16u : 0u;
+#pragma unroll
+            for (int u = 0; u < WB / 1024; ++u) {
+                const PWA_GLOBAL uint32_t* g = (const PWA_GLOBAL uint32_t*)(tb + off0 + (size_t)(u / 4) * 4096 + voff[u % NPH]);
+                __attribute__((address_space(3))) uint32_t* l = (__attribute__((address_space(3))) uint32_t*)(win + buf * WB + (u / 4) * 4096);
+                if (u % 4 == 0) __builtin_amdgcn_global_load_lds(g, l, 16, 0, PWA_WALK_LOAD_AUX);
+                if (u % 4 == 1) __builtin_amdgcn_global_load_lds(g, l, 16, 1024, PWA_WALK_LOAD_AUX);
+                if (u % 4 == 2) __builtin_amdgcn_global_load_lds(g, l, 16, 2048, PWA_WALK_LOAD_AUX);
+                if (u % 4 == 3) __builtin_amdgcn_global_load_lds(g, l, 16, 3072, PWA_WALK_LOAD_AUX);
+            }
+            return;
+        }
         // (four pieces per address pair: the instruction's immediate offset moves the global and the LDS address alike)
 #pragma unroll
         for (int u = 0; u < WB / 4096; ++u) {
@@ -875,6 +926,13 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
         for (int u = (WB / 4096) * 4; u < WB / 1024; ++u)   // (RL = 2: 8 KiB windows are whole multiples of 4 KiB as well; nothing left)
             __builtin_amdgcn_global_load_lds((const PWA_GLOBAL uint32_t*)(tb + off0 + (size_t)u * 1024 + lane * 16),
                                              (__attribute__((address_space(3))) uint32_t*)(win + buf * WB + u * 1024), 16, 0, PWA_WALK_LOAD_AUX);
+    };
+    int klo0 = 0, klo1 = 0;   // NARROW: the lowest band lane staged in LDS buffer 0 / 1 (wave-uniform)
+    auto klo_of = [&](int buf) { return buf ? klo1 : klo0; };
+    auto set_klo = [&](int buf, int v) {
+        v = __builtin_amdgcn_readfirstlane(v);
+        klo0 = buf ? klo0 : v;
+        klo1 = buf ? v : klo1;
     };
     // ---- the walk.  Per trip the 64 lanes look at the 64 cells of the DIAGONAL through (i, j):
     // lane d reads the code of (i-d, j-d).  The leading run of 'd' codes is one run of 'M' ops,
@@ -932,16 +990,21 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
                 const unsigned q0 = (unsigned)(i - 1);
                 const int s0 = Geo::stripe(q0), k0 = Geo::lane(Geo::row_in_stripe(q0));
                 const int w0 = (int)((unsigned)(j - 1 + k0) / (unsigned)WIN);
-                if (s0 != cur_s || w0 != cur_w) {
-                    if (!(s0 == pre_s && w0 == pre_w)) issue(w0 & 1, s0, w0);   // not the window already in flight / landed
-                    if (!(s0 == pre_s && w0 == pre_w && pre_done)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA is ordered for our ds_read by vmcnt
+                if (s0 != cur_s || w0 != cur_w || (NARROW && k0 < klo_of(w0 & 1))) {   // (NARROW: ... or the anchor has left the staged lanes)
+                    const bool have = s0 == pre_s && w0 == pre_w && (!NARROW || k0 >= klo_of(w0 & 1));   // the window already in flight / landed
+                    if (!have) {
+                        issue(w0 & 1, s0, w0, k0 - DW, k0);
+                        set_klo(w0 & 1, k0 - DW);
+                    }
+                    if (!(have && pre_done)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA is ordered for our ds_read by vmcnt
                     cur_s = s0;
                     cur_w = w0;
                     pre_s = -1;
                     pre_done = false;
                     since = 0;
                     if (w0 > 0) {
-                        issue((w0 - 1) & 1, s0, w0 - 1);
+                        issue((w0 - 1) & 1, s0, w0 - 1, k0 - 2 * DW, k0);
+                        set_klo((w0 - 1) & 1, k0 - 2 * DW);
                         pre_s = s0;
                         pre_w = w0 - 1;
                     }
@@ -955,13 +1018,17 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
             const unsigned span = (unsigned)((cur_w + 1) * WIN - tlo);
             auto staged = [&](int t) { return (unsigned)(t - tlo) < span; };
             auto lds_at = [&](int t, int ql) { return (t & (2 * WIN - 1)) * SR + Geo::off(ql); };
+            // NARROW (single-stripe pairs): rows below the anchor window's lowest staged lane count as not staged -- one range check in
+            // place of the stripe compare (the window behind it holds lanes from even further down: a trip just ends a little earlier)
+            const int kr = NARROW ? max(0, klo_of(cur_w & 1)) * RL : 0;
             int code[NV];
             int qlo0 = 0, t0 = 0;
             bool s0v = false;
 #pragma unroll
             for (int r = 0; r <= A; ++r) {                                   // view A - r: the cell r rows above (i-d, j-d)
                 const int q = i - 1 - r - dl, ql = Geo::row_in_stripe((unsigned)q);
-                const bool same = Geo::stripe((unsigned)q) == cur_s;         // same stripe (false for rows above the matrix)
+                const bool same = NARROW ? (unsigned)(q - kr) < (unsigned)(SR - kr) && cur_s == 0
+                                         : Geo::stripe((unsigned)q) == cur_s;         // same stripe (false for rows above the matrix)
                 const int t = jj - 1 + Geo::lane(ql);                        // its band step
                 code[A - r] = win[same && staged(t) && jj > 0 ? lds_at(t, ql) : NOCODE];
                 if (r == 0) {
@@ -1106,15 +1173,19 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
             const unsigned q0 = (unsigned)(i - 1);
             const int s0 = Geo::stripe(q0), k0 = Geo::lane(Geo::row_in_stripe(q0));
             const int w0 = (j - 1 + k0) / WIN;
-            if (s0 != cur_s || w0 != cur_w) {
-                if (s0 == pre_s && w0 == pre_w) cb ^= 1;                 // already in flight into the other buffer
-                else issue(cb, s0, w0);
+            if (s0 != cur_s || w0 != cur_w || (NARROW && k0 < klo_of(cb))) {
+                if (s0 == pre_s && w0 == pre_w && (!NARROW || k0 >= klo_of(cb ^ 1))) cb ^= 1;   // already in flight into the other buffer
+                else {
+                    issue(cb, s0, w0, k0 - DW, k0);
+                    set_klo(cb, k0 - DW);
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // LDS-DMA is ordered for our ds_read by vmcnt
                 cur_s = s0;
                 cur_w = w0;
                 pre_s = -1;
                 if (w0 > 0) {                                            // the walk only moves backwards
-                    issue(cb ^ 1, s0, w0 - 1);
+                    issue(cb ^ 1, s0, w0 - 1, k0 - 2 * DW, k0);
+                    set_klo(cb ^ 1, k0 - 2 * DW);
                     pre_s = s0;
                     pre_w = w0 - 1;
                 }
@@ -1128,7 +1199,7 @@ __global__ __launch_bounds__(64) void pair_traceback_kernel(const PairParams G) 
                 const int s = Geo::stripe(q), ql = Geo::row_in_stripe(q);
                 const int t = cj - 1 + Geo::lane(ql);
                 const int w = t / WIN;
-                if (s == cur_s && w == cur_w) c = win[cb * WB + (t - w * WIN) * STEP_BYTES + Geo::off(ql)];
+                if (s == cur_s && w == cur_w && (!NARROW || (int)q >= klo_of(cb) * RL)) c = win[cb * WB + (t - w * WIN) * STEP_BYTES + Geo::off(ql)];
             }
             return c;
         };
