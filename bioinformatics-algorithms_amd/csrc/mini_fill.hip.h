@@ -68,6 +68,11 @@ __device__ __forceinline__ void mini_chunk(const int t0, const int k, const int 
     static_assert(!GAP0 || (!LOCAL && !SBAND && PU == 0), "gap-shifted fills: global, no score band");
     static_assert(LN == 16 || (LN == 64 && (RL == 6 || RL == 8 || RL == 12 || RL == 16)), "one pair per wave: single stripes of 384 .. 1024 rows");
     const int cu = p_addw(cl, PU - PL);
+    // LOCAL: the first maximum of every row (hw2.cpp:225-229).  Inside the chunk a row keeps ONE running maximum over keys H * 16 + (15 - q)
+    // -- value first, then the earlier step -- built with a v_lshl_or and folded two steps at a time by a v_max3; the row's record
+    // (bs: such a key, bj: the chunk it is from) takes it at the end of the chunk if its H is strictly larger.  1.75 instead of 3
+    // instructions per cell (compare + two selects).  H * 16 needs |H| < 2^26 (the host checks).
+    int cmax[RL];
     static_for<0, 16>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         const int j = t0 + q - k + 1;
@@ -95,10 +100,9 @@ __device__ __forceinline__ void mini_chunk(const int t0, const int k, const int 
             if (r % 4 == 3) tb_put_code<3>(codes[r / 4], kk);
             const int hn = GAP0 ? (base | PL) : p_addw(base, cl);                   // what the next column (left) and the diagonal take
             if (LOCAL) {
-                if (act && base > bs[r]) {                                          // hw2.cpp:225-229 (bs holds H * 4)
-                    bs[r] = base;
-                    bj[r] = j;
-                }
+                int key = (int)(((unsigned)base << 2) | (unsigned)(15 - q));
+                if (GUARD) key = act ? key : 0;                                     // (a lane outside its matrix records nothing)
+                cmax[r] = q == 0 ? key : max(cmax[r], key);
             }
             if (SBAND) hsb[r] = kk >> 2;
             dg = kl;
@@ -125,6 +129,14 @@ __device__ __forceinline__ void mini_chunk(const int t0, const int k, const int 
         }
         }
     });
+    if (LOCAL) {
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {
+            const bool better = cmax[r] > (bs[r] | 15);                             // strictly larger H: the earlier chunk keeps a tie
+            bs[r] = better ? cmax[r] : bs[r];
+            bj[r] = better ? t0 : bj[r];
+        }
+    }
 }
 
 // A workgroup = FOUR waves, each running its own tasks -- four only so that the launch can be balanced: the host asks for as much (unused)
@@ -247,14 +259,14 @@ __global__ __launch_bounds__(64 * kMiniWaves) void mini_fill_kernel(const PairPa
                 if (i_first + r == n) res->score = (int)((unsigned)hl[r] - (unsigned)cl) >> 2;
         } else {
             // per-lane reduction over row slots, then over the pair's 16 lanes: max score, then smallest i (hw2.cpp:225-229)
-            int s_best = 0, i_best = 0, j_best = 0;
+            int s_best = 0, i_best = 0, j_best = 0;   // (bs[r]: H * 16 + 15 - q, bj[r]: the chunk's first step -- mini_chunk)
 #pragma unroll
             for (int r = 0; r < RL; ++r) {
-                const int i = i_first + r;
-                if (i <= n && bs[r] > s_best) {
-                    s_best = bs[r];
+                const int i = i_first + r, h = bs[r] >> 4;
+                if (i <= n && h > s_best) {
+                    s_best = h;
                     i_best = i;
-                    j_best = bj[r];
+                    j_best = bj[r] + (15 - (bs[r] & 15)) - k + 1;
                 }
             }
 #pragma unroll
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(64 * kMiniWaves) void mini_fill_kernel(const PairPa
             }
             if (k == 0) {
                 g_i32* bp = (g_i32*)(G.best + P->first_stripe);
-                bp[0] = s_best >> 2;
+                bp[0] = s_best;
                 bp[1] = i_best;
                 bp[2] = j_best;
                 bp[3] = 0;

@@ -289,10 +289,11 @@ void for_seq_ranges(const uint64_t* seq_off, uint32_t n_seq, F&& fn, int* n_thre
 }
 
 // The traceback kernels keep H * 4 + priority in int32 (pair_fill.hip.h): |H| has to stay below 2^28.
-bool tb_range_ok(uint64_t n_plus_m, int match, int mismatch, int gap) {
+// (bits = 26: local fills of the mini-stripe kernels, whose first-maximum records hold H * 16 + a step index, mini_fill.hip.h)
+bool tb_range_ok(uint64_t n_plus_m, int match, int mismatch, int gap, int bits = 28) {
     const uint64_t amax = (uint64_t)std::max<int64_t>({std::llabs((long long)match), std::llabs((long long)mismatch),
                                                        std::llabs((long long)gap), 1});
-    return (n_plus_m + 2) <= (1ull << 28) / amax;
+    return (n_plus_m + 2) <= (1ull << bits) / amax;
 }
 
 // A workspace of `bytes` from the context's cache slot (see pwa_ctx): reused when big enough, regrown otherwise;
@@ -984,7 +985,7 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
     // Short patterns that a scores pass routes away from the strips run on the mini-stripe engine WITHOUT a band (mini_fill.hip.h,
     // BAND = false: four pairs per wave) where it applies: coded arena, keyed cells in range, table constants in a byte.
     bool mini_scores = false, mini_gap0 = false;
-    if (arena_coded && !affine && !nwdist && ctx->knobs.tb_engine != 0 && tb_range_ok(max_n + max_m, match, mismatch, gap)) {
+    if (arena_coded && !affine && !nwdist && ctx->knobs.tb_engine != 0 && tb_range_ok(max_n + max_m, match, mismatch, gap, local ? 26 : 28)) {
         const int64_t kdm = ((int64_t)match - gap) * 4 + 2, kdx = ((int64_t)mismatch - gap) * 4 + 2;
         mini_scores = kdm <= 127 && kdm >= -126 && kdx <= 127 && kdx >= -126;
         if (mini_scores && !local) {
@@ -2170,7 +2171,8 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     }
     const int k_match = gap0 ? match - 2 * gap : match, k_mismatch = gap0 ? mismatch - 2 * gap : mismatch, k_gap = gap0 ? 0 : gap;
     // the mini-stripe engine exists for keyed cells with table scoring; PWA_FORCE_RL / PWA_FORCE_W address the stripe engine
-    const bool mini_ok = coded && keyed && ctx->knobs.tb_engine != 0 && !ctx->knobs.force_rl && !ctx->knobs.force_w;
+    const bool mini_ok = coded && keyed && ctx->knobs.tb_engine != 0 && !ctx->knobs.force_rl && !ctx->knobs.force_w &&
+                         (!local || tb_range_ok(longest_sum, match, mismatch, gap, 26));
     // patterns of 257 .. 1024 rows: ONE wave per pair (mini-stripe kernels with 64 lanes per pair, RL = 8 | 16) instead of 4 - 8 pipelined
     // stripes -- when the call has enough of them to occupy the chip that way (a few such pairs are faster spread over more waves)
     uint64_t n_mid = 0;
@@ -2533,7 +2535,8 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     const int64_t kd_match = ((int64_t)match - gap) * 4 + 2, kd_mismatch = ((int64_t)mismatch - gap) * 4 + 2;
     const bool coded = n_alpha <= 7 && kd_match <= 127 && kd_match >= -126 && kd_mismatch <= 127 && kd_mismatch >= -126 && !ctx->knobs.no_pair_table;
     int mini_rl = 0, wide_rl = 0;   // wide: one pair per wave (PWA_TB_ENGINE=2 here: a single pair would normally take pipelined stripes)
-    if (coded && keyed && ctx->knobs.tb_engine != 0 && !ctx->knobs.force_rl && !ctx->knobs.force_w) {
+    if (coded && keyed && ctx->knobs.tb_engine != 0 && !ctx->knobs.force_rl && !ctx->knobs.force_w &&
+        (mode != PWA_MODE_SW || tb_range_ok(n + m, match, mismatch, gap, 26))) {
         if (n <= 256) {
             for (const int rl : kMiniRL)
                 if (!mini_rl && n <= (uint64_t)(16 * rl)) mini_rl = rl;
