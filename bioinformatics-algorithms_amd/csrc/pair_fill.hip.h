@@ -369,6 +369,10 @@ __device__ __forceinline__ void keyed_chunk(const int t0, const int lane, const 
     int tdead = tch;                             // a register whose value is dead: destination of the next text pick
     constexpr int P = 3 * RL;                    // filler slots of a step: after each of the 3 chain instructions of each row
     constexpr int F_FILL = P > 3 ? 3 : P - 1;    // slot of the wave_shr:1 half of the next text symbol: >= 3 instructions after its lane-0 pick
+    // LOCAL: every row's first maximum (hw2.cpp:225-229) through ONE running maximum per chunk over keys H * 16 + (15 - q) -- value first,
+    // then the earlier step; the row's record (bs: such a key, bj: the chunk's first step) takes it after the chunk if its H is strictly
+    // larger (mini_fill.hip.h has the same; r03).  H * 16: the host keeps local keyed fills below 2^26.
+    int cmax[RL];
     static_for<0, kCHsteps>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr bool more = q + 1 < kCHsteps;
@@ -422,10 +426,9 @@ __device__ __forceinline__ void keyed_chunk(const int t0, const int lane, const 
             hn[r] = GAP0 ? (base | PL) : p_addw(base, cl);                       // what the next column (left) and the diagonal take
             chores(3 * r + 2);
             if (LOCAL) {
-                if (act && base > bs[r]) {                                       // hw2.cpp:225-229 (bs holds H * 4)
-                    bs[r] = base;
-                    bj[r] = j;
-                }
+                int key = (int)(((unsigned)base << 2) | (unsigned)(kCHsteps - 1 - q));
+                if (GUARD) key = act ? key : 0;                                  // (a lane outside the matrix records nothing)
+                cmax[r] = q == 0 ? key : max(cmax[r], key);
             }
             PWA_SB();
         }
@@ -457,6 +460,15 @@ __device__ __forceinline__ void keyed_chunk(const int t0, const int lane, const 
         s4 = s4n;
         PWA_SB();
     });
+    if (LOCAL) {
+        static_assert(kCHsteps == 16, "four key bits for the step inside its chunk");
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {
+            const bool better = cmax[r] > (bs[r] | 15);                          // strictly larger H: the earlier chunk keeps a tie
+            bs[r] = better ? cmax[r] : bs[r];
+            bj[r] = better ? t0 : bj[r];
+        }
+    }
     tch = tn;
 }
 
@@ -745,10 +757,12 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
 #pragma unroll
                 for (int r = 0; r < RL; ++r) {
                     const int i = i_first + r;
-                    if (i <= n && bs[r] > s_best) {   // slots in increasing i: strict '>' keeps the smallest i
-                        s_best = bs[r];
+                    // keyed fills: bs[r] = H * 16 + 15 - q, bj[r] = the chunk's first step (keyed_chunk); plain fills: H and j
+                    const int h = TBK ? (bs[r] >> 4) : bs[r];
+                    if (i <= n && h > s_best) {   // slots in increasing i: strict '>' keeps the smallest i
+                        s_best = h;
                         i_best = i;
-                        j_best = bj[r];
+                        j_best = TBK ? bj[r] + (15 - (bs[r] & 15)) - lane + 1 : bj[r];
                     }
                 }
 #pragma unroll
@@ -759,7 +773,7 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                 }
                 if (lane == 0) {
                     g_i32* bp = (g_i32*)(G.best + P.first_stripe + s);
-                    bp[0] = TBK ? (s_best >> 2) : s_best;   // the keyed traceback kernels track H * 4
+                    bp[0] = s_best;
                     bp[1] = i_best;
                     bp[2] = j_best;
                     bp[3] = 0;

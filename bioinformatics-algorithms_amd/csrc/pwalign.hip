@@ -2158,7 +2158,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     uint64_t longest_sum = 0;
     for (uint64_t k = 0; k < n_pairs; ++k) longest_sum = std::max(longest_sum, slen(pair_a[k]) + slen(pair_b[k]));
     // scores x lengths beyond the packed keys' 2^28: the plain int32 form, exact for anything the reference's int holds
-    const bool keyed = tb_range_ok(longest_sum, match, mismatch, gap) && !ctx->knobs.no_keyed_tb;
+    const bool keyed = tb_range_ok(longest_sum, match, mismatch, gap, local ? 26 : 28) && !ctx->knobs.no_keyed_tb;   // (local: H * 16 in the first-maximum records)
     // Global alignments with table scoring run in gap-shifted coordinates G = H - gap (i + j): the same recurrence with gap 0 and
     // scores s - 2 gap, identical comparisons and codes, one instruction less per cell (pair_fill.hip.h, GAP0).  |G| <= |H| +
     // |gap| (n + m): twice the range; both shifted diagonal constants must fit the byte table.
@@ -2505,7 +2505,7 @@ int pwa_align_matrices(pwa_ctx* ctx, int mode, int match, int mismatch, int gap,
     if (mode != PWA_MODE_NW && mode != PWA_MODE_SW) return fail(ctx, PWA_E_INVALID, "unknown mode");
     if ((n && !pattern) || (m && !text) || (!dp_out && !tb_out)) return fail(ctx, PWA_E_INVALID, "null input");
     if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
-    const bool keyed = tb_range_ok(n + m, match, mismatch, gap) && !ctx->knobs.no_keyed_tb;
+    const bool keyed = tb_range_ok(n + m, match, mismatch, gap, mode == PWA_MODE_SW ? 26 : 28) && !ctx->knobs.no_keyed_tb;
     const bool local = mode == PWA_MODE_SW;
     const uint64_t W = m + 1;
     // row 0 and column 0 exactly as the reference initialises them (hw2.cpp:119-136 / 193-194)
