@@ -72,7 +72,7 @@ __device__ __forceinline__ void mini_chunk(const int t0, const int k, const int 
     // -- value first, then the earlier step -- built with a v_lshl_or and folded two steps at a time by a v_max3; the row's record
     // (bs: such a key, bj: the chunk it is from) takes it at the end of the chunk if its H is strictly larger.  1.75 instead of 3
     // instructions per cell (compare + two selects).  H * 16 needs |H| < 2^26 (the host checks).
-    int cmax[RL];
+    int cmax[RL], kprev[RL];
     static_for<0, 16>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         const int j = t0 + q - k + 1;
@@ -102,7 +102,13 @@ __device__ __forceinline__ void mini_chunk(const int t0, const int k, const int 
             if (LOCAL) {
                 int key = (int)(((unsigned)base << 2) | (unsigned)(15 - q));
                 if (GUARD) key = act ? key : 0;                                     // (a lane outside its matrix records nothing)
-                cmax[r] = q == 0 ? key : max(cmax[r], key);
+                // two steps per update (one v_max3), pinned in program order: left to itself hipcc turns the 16 maxima of a row into a
+                // tree and keeps every key of the chunk alive for it (RL = 10: 256 VGPRs + AGPR moves, one wave per SIMD)
+                if (q % 2 == 0) kprev[r] = key;
+                else {
+                    cmax[r] = q == 1 ? max(kprev[r], key) : max(max(cmax[r], kprev[r]), key);
+                    asm volatile("" : "+v"(cmax[r]));
+                }
             }
             if (SBAND) hsb[r] = kk >> 2;
             dg = kl;

@@ -372,7 +372,7 @@ __device__ __forceinline__ void keyed_chunk(const int t0, const int lane, const 
     // LOCAL: every row's first maximum (hw2.cpp:225-229) through ONE running maximum per chunk over keys H * 16 + (15 - q) -- value first,
     // then the earlier step; the row's record (bs: such a key, bj: the chunk's first step) takes it after the chunk if its H is strictly
     // larger (mini_fill.hip.h has the same; r03).  H * 16: the host keeps local keyed fills below 2^26.
-    int cmax[RL];
+    int cmax[RL], kprev[RL];
     static_for<0, kCHsteps>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr bool more = q + 1 < kCHsteps;
@@ -428,7 +428,13 @@ __device__ __forceinline__ void keyed_chunk(const int t0, const int lane, const 
             if (LOCAL) {
                 int key = (int)(((unsigned)base << 2) | (unsigned)(kCHsteps - 1 - q));
                 if (GUARD) key = act ? key : 0;                                  // (a lane outside the matrix records nothing)
-                cmax[r] = q == 0 ? key : max(cmax[r], key);
+                // two steps per update (one v_max3), pinned in program order: left to itself hipcc turns the 16 maxima of a row into a
+                // tree and keeps every key of the chunk alive for it (RL = 10: 256 VGPRs + AGPR moves, one wave per SIMD)
+                if (q % 2 == 0) kprev[r] = key;
+                else {
+                    cmax[r] = q == 1 ? max(kprev[r], key) : max(max(cmax[r], kprev[r]), key);
+                    asm volatile("" : "+v"(cmax[r]));
+                }
             }
             PWA_SB();
         }

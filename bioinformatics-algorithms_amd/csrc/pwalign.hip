@@ -67,6 +67,7 @@ struct Knobs {
     int force_r = 0, force_mode = -1;           // PWA_FORCE_R, PWA_FORCE_MODE: strip height / kernel form of the strip engine
     uint64_t arena_limit = 0;                   // PWA_ARENA_LIMIT: bytes of sequence arena per run of the one-shot calls (tests)
     uint64_t lane_rows_limit = 0;               // PWA_LANE_ROWS_LIMIT: bytes of per-lane text rows per batch object (tests)
+    uint64_t range_bytes = 0;                   // PWA_RANGE_BYTES: band + op bytes per range of pwa_align_batch / pwa_overlaps (tests: several ranges on small lists)
     bool no_pair_table = false;                 // PWA_NO_PAIR_TABLE: traceback fills on raw bytes (compare + select)
     bool no_keyed_tb = false;                   // PWA_NO_KEYED_TB: traceback fills in the plain int32 form
     bool no_gap_shift = false;                  // PWA_NO_GAP_SHIFT: global traceback fills in H, not G = H - gap (i + j)
@@ -96,6 +97,7 @@ struct Knobs {
         force_mode = num("PWA_FORCE_MODE", -1);
         if (const char* e = std::getenv("PWA_ARENA_LIMIT")) arena_limit = std::max<uint64_t>(1024, std::strtoull(e, nullptr, 10));
         if (const char* e = std::getenv("PWA_LANE_ROWS_LIMIT")) lane_rows_limit = std::max<uint64_t>(1024, std::strtoull(e, nullptr, 10));
+        if (const char* e = std::getenv("PWA_RANGE_BYTES")) range_bytes = std::max<uint64_t>(4096, std::strtoull(e, nullptr, 10));
         no_pair_table = flag("PWA_NO_PAIR_TABLE");
         no_keyed_tb = flag("PWA_NO_KEYED_TB");
         no_gap_shift = flag("PWA_NO_GAP_SHIFT");
@@ -2252,6 +2254,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     // cut into EQUAL ones, not into full ones and a remainder.
     const uint64_t band_mult = ctx->score_band ? 5 : 1;
     uint64_t chunk_target = std::min<uint64_t>(budget, 8ull << 30);
+    uint64_t pairs_target = ~0ull;   // live pairs per range, when the list is cut into several
     {
         uint64_t total = 0, live = 0;
         for (uint64_t k = 0; k < n_pairs; ++k) {
@@ -2261,11 +2264,20 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
             ++live;
         }
         if (live) {
-            const uint64_t cap = std::min<uint64_t>(budget, 48ull << 30);
+            const uint64_t cap = ctx->knobs.range_bytes ? ctx->knobs.range_bytes : std::min<uint64_t>(budget, 48ull << 30);
             const uint64_t for_8192 = (uint64_t)((long double)total / (long double)live * 8192.0L);
             chunk_target = std::min<uint64_t>(cap, std::max<uint64_t>(chunk_target, for_8192));
             const uint64_t n_ranges = (total + chunk_target - 1) / chunk_target;
-            if (n_ranges > 1) chunk_target = std::min<uint64_t>(cap, total / n_ranges + total / live + (1ull << 20));   // equal shares (+ one average pair)
+            if (n_ranges > 1) {
+                chunk_target = std::min<uint64_t>(cap, total / n_ranges + total / live + (1ull << 20));   // equal shares (+ one average pair)
+                // ... counted in PAIRS, in whole rounds of the chip: a launch lasts as long as its busiest wave, and 8193 pairs are 2049
+                // tasks for 2048 wave slots -- [gpu, r03] 16 384 pairs 150 x 10k cut 8193 + 8191: the first fill took 4.1 ms, the second 3.0
+                pairs_target = (live + n_ranges - 1) / n_ranges;
+                if (pairs_target > 4096) pairs_target = (pairs_target + 4095) / 4096 * 4096;   // 1024 waves of four pairs (or 4 x 1024 of one)
+                const uint64_t fit = cap / std::max<uint64_t>(total / live, 1);
+                if (pairs_target > fit) pairs_target = std::max<uint64_t>(fit / 4096 * 4096, std::min<uint64_t>(fit, 4096));
+                chunk_target = std::min<uint64_t>(cap, std::max<uint64_t>(chunk_target, (uint64_t)((long double)total / (long double)live * (long double)pairs_target * 1.02L)));
+            }
         }
     }
     mark("plan: memory + range size");
@@ -2286,12 +2298,13 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     std::vector<Range> ranges;
     uint64_t band_cap = 0, ops_cap_b = 0, nc_cap = 0;
     for (uint64_t k0 = 0; k0 < n_pairs;) {
-        uint64_t k1 = k0, est = 0, opsb = 0;
+        uint64_t k1 = k0, est = 0, opsb = 0, live_in = 0;
         while (k1 < n_pairs) {
             const uint64_t n = slen(pair_a[k1]), m = slen(pair_b[k1]);
             if (n > 0x7fffffc0ull || m > 0x7fffffc0ull) return fail(ctx, PWA_E_CAPACITY, "sequence longer than 2^31");
             const uint64_t need = (n && m) ? align_up(band_of(class_of(n), n, m), 256) : 0;
-            if (k1 > k0 && (est + need) * band_mult + opsb + n + m > chunk_target) break;
+            if (k1 > k0 && ((est + need) * band_mult + opsb + n + m > chunk_target || (need && live_in >= pairs_target))) break;
+            live_in += need != 0;
             est += need;
             opsb += align_up(n + m + 1, 16);
             ++k1;

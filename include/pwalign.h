@@ -40,6 +40,7 @@
  *   PWA_TB_ENGINE=0               traceback fills: stripe engine only (default: mini-stripe engine for patterns of <= 256 rows)
  *   PWA_NO_PIPELINE, PWA_PIPE_RUNS=N  one-shot score calls: runs strictly one after the other / a list that fits one arena cut into N runs
  *   PWA_ARENA_LIMIT, PWA_LANE_ROWS_LIMIT   bytes per run of the one-shot calls / per-lane text rows per batch (force the multi-run paths)
+ *   PWA_RANGE_BYTES               band + op bytes per range of pwa_align_batch / pwa_overlaps (forces several ranges on a small list)
  *   PWA_NO_PAIR_TABLE, PWA_NO_KEYED_TB, PWA_NO_GAP_SHIFT, PWA_NO_TILED_OPS, PWA_NO_PACKED_DIST, PWA_PAIRED, PWA_FORCE_LANES,
  *   PWA_FORCE_R, PWA_FORCE_MODE, PWA_FORCE_RL, PWA_FORCE_W, PWA_WG_PER_CU, PWA_NO_LDS_PAD, PWA_STAMPS, PWA_TRACE_STRIPE
  *                                 select one of several equivalent kernel forms / geometries, or record time stamps

@@ -1119,6 +1119,32 @@ def test_lists_of_long_patterns_take_taller_stripes(ctx):
             assert (scores[k], ovl[k]) == (want["score"], want["overlap"]), (mode, k)
 
 
+def test_align_batch_cut_into_several_ranges():
+    """pwa_align_batch / pwa_overlaps on a list whose bands do not fit one range (PWA_RANGE_BYTES: 3 MB here; at full size the free
+    HBM decides): ranges of equal pair counts, every class present in several of them, results in caller order."""
+    rng = random.Random(8192)
+    seqs, pa, pb = [], [], []
+    for k in range(260):
+        n = rng.choice([1, 20, 64, 65, 100, 150, 151, 256, 300, 700])
+        p = O.gen(64, 0, k, n)
+        t = _mutate(rng, p, 0.15)[:rng.randint(1, 400)] if k % 3 else O.gen(64, 1, k, rng.randint(1, 500))
+        seqs.extend([p, t])
+        pa.append(len(seqs) - 2)
+        pb.append(len(seqs) - 1)
+    seqs.append(b"")
+    pa.append(len(seqs) - 1)
+    pb.append(0)
+    with switched_context(PWA_RANGE_BYTES=str(3 << 20)) as c, switched_context() as whole:
+        for mode in ("nw", "sw"):
+            res = c.align_batch(mode, seqs, pa, pb, 2, -3, -5)
+            assert res == whole.align_batch(mode, seqs, pa, pb, 2, -3, -5)
+            assert c.overlaps(mode, seqs, pa, pb, 2, -3, -5) == whole.overlaps(mode, seqs, pa, pb, 2, -3, -5)
+            for k, r in enumerate(res):
+                want = O.align(mode, seqs[pa[k]], seqs[pb[k]], 2, -3, -5, compact=True)
+                assert (r["score"], r["ops"], tuple(r["end"]), tuple(r["start"])) == \
+                    (want["score"], want["ops"], tuple(want["end"]), tuple(want["start"])), (mode, k)
+
+
 @pytest.mark.parametrize("how", ["padded regions", "PWA_NO_TILED_OPS"])
 def test_op_lists_through_the_staging_copy(how):
     """pwa_align_batch with op regions that do NOT follow one another without a gap (a C caller with aligned regions), and with the
