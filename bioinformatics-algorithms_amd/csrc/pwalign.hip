@@ -67,6 +67,7 @@ struct Knobs {
     int force_r = 0, force_mode = -1;           // PWA_FORCE_R, PWA_FORCE_MODE: strip height / kernel form of the strip engine
     uint64_t arena_limit = 0;                   // PWA_ARENA_LIMIT: bytes of sequence arena per run of the one-shot calls (tests)
     uint64_t lane_rows_limit = 0;               // PWA_LANE_ROWS_LIMIT: bytes of per-lane text rows per batch object (tests)
+    int mini_per_cu = 0;                        // PWA_MINI_PER_CU: most four-wave workgroups of a mini-stripe fill per CU (experiments; default 2)
     uint64_t range_bytes = 0;                   // PWA_RANGE_BYTES: band + op bytes per range of pwa_align_batch / pwa_overlaps (tests: several ranges on small lists)
     bool no_pair_table = false;                 // PWA_NO_PAIR_TABLE: traceback fills on raw bytes (compare + select)
     bool no_keyed_tb = false;                   // PWA_NO_KEYED_TB: traceback fills in the plain int32 form
@@ -97,6 +98,7 @@ struct Knobs {
         force_mode = num("PWA_FORCE_MODE", -1);
         if (const char* e = std::getenv("PWA_ARENA_LIMIT")) arena_limit = std::max<uint64_t>(1024, std::strtoull(e, nullptr, 10));
         if (const char* e = std::getenv("PWA_LANE_ROWS_LIMIT")) lane_rows_limit = std::max<uint64_t>(1024, std::strtoull(e, nullptr, 10));
+        mini_per_cu = num("PWA_MINI_PER_CU", 0);
         if (const char* e = std::getenv("PWA_RANGE_BYTES")) range_bytes = std::max<uint64_t>(4096, std::strtoull(e, nullptr, 10));
         no_pair_table = flag("PWA_NO_PAIR_TABLE");
         no_keyed_tb = flag("PWA_NO_KEYED_TB");
@@ -583,7 +585,9 @@ struct PairLaunch {
             // per_cu = ceil(workgroups / CUs), at most 2; longer task lists run in rounds ([gpu] pairs 150 x 10k: 8192 of them at two
             // waves per SIMD 2.68 ms, 16384 at four 6.61 ms -- 16 k concurrent write streams get 4.0 instead of 4.9 TB/s out of HBM).
             const uint32_t n_wg = (G.n_tasks + kMiniWaves - 1) / kMiniWaves;
-            const uint32_t per_cu = std::min<uint32_t>(2, (n_wg + (uint32_t)ctx->num_cu - 1) / (uint32_t)ctx->num_cu);
+            // (band-less fills have no write streams to thin out: four per CU -- [gpu] scores with end cells 2 - 3 % faster than at two)
+            const uint32_t cap_per_cu = ctx->knobs.mini_per_cu > 0 ? (uint32_t)std::min(ctx->knobs.mini_per_cu, 5) : (tb ? 2u : 4u);
+            const uint32_t per_cu = std::min<uint32_t>(cap_per_cu, (n_wg + (uint32_t)ctx->num_cu - 1) / (uint32_t)ctx->num_cu);
             static const uint32_t kPadKiB[6] = {0, 96, 64, 48, 36, 30};   // more than 160 KiB / (per_cu + 1), at most 160 KiB / per_cu
             const size_t pad_lds = (size_t)kPadKiB[per_cu] * 1024;
             HIPC(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds));
