@@ -1162,8 +1162,8 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
                 for (uint32_t l = 0; l < ht[t].count; ++l) {
                     const uint32_t k = order[ht[t].first + l];
                     const uint64_t n = slen(pair_a[k]), m = slen(pair_b[k]);
-                    if (const int mrl = mini_rl_of(n)) {   // mini-stripe engine, no band: a quarter of a wave, (17 + 5 | 8.5 RL) instructions per step
-                        const double mstep = (17.0 + (local ? 8.5 : 5.0) * mrl) * 1.37;   // [gpu] 92 ns per step for RL = 10, global (tools/probes/mini_mix.hip)
+                    if (const int mrl = mini_rl_of(n)) {   // mini-stripe engine, no band: a quarter of a wave, (17 + 5 | 7.3 RL) instructions per step
+                        const double mstep = (17.0 + (local ? 7.3 : 5.0) * mrl) * 1.37;   // [gpu] 92 ns per step for RL = 10, global (tools/probes/mini_mix.hip)
                         steps += (double)(m + 15) * mstep / 4.0 / 1.5;                    // (two waves per SIMD: ~1.9 x one wave's throughput)
                         lat = std::max(lat, (double)(m + 15) * mstep * 1e-3);
                         continue;
