@@ -31,7 +31,7 @@ const BatchKernelEntry* find_batch_kernel(int R, int mode, int score);
 // pair_kernels.hip
 // perm: coded sequences, table scoring (keyed tb only); keyed = false: the plain int32 traceback form (RL = 4 only)
 // gap0: global fill in gap-shifted coordinates (the host passes gap 0 and scores s - 2 gap): perm && keyed && !sband only
-pair_kernel_t pair_fill_kernel_for(int rl, int w, bool local, bool tb, bool sband, bool perm, bool keyed = true, bool gap0 = false);
+pair_kernel_t pair_fill_kernel_for(int rl, int w, bool local, bool tb, bool sband, bool perm, bool keyed = true, bool gap0 = false, bool band = true);   // band = false: keyed, table scoring, no band at all
 pair_kernel_t pair_traceback_kernel_for(int rl, bool local, int walk);   // walk: WALK_NONE / WALK_OPS / WALK_OVERLAP
 // mini_kernels*.hip -- the mini-stripe engine (16 lanes per pair, 4 pairs per wave; keyed cells, table scoring): fills for
 // rl in kMiniRL; gap0 only global without score band; the walks over its band geometry (BandGeo<16, rl>)

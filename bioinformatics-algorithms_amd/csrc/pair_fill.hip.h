@@ -39,7 +39,7 @@
 namespace pwa {
 
 // Traceback codes = the direction's PRIORITY in the reference's tie-break, so that they can ride in the two low bits
-// of a packed key (see stripe_step): global (hw2.cpp:142-153) prefers diag, then left, then up; local (211-222)
+// of a packed key (see keyed_chunk): global (hw2.cpp:142-153) prefers diag, then left, then up; local (211-222)
 // prefers the zero floor, then diag, then up, then left.
 enum { TB_DIAG = 2, TB_STOP = 3 };
 template <bool LOCAL> struct TbCode {
@@ -174,46 +174,9 @@ __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i
     if (active) {
         const int j = c + 1;
         int dg = diag0, up = up_in;
-        if (TB && KEYED) {
-            // keyed form: candidates are built with fast-class adds, ONE v_max3 replaces the two compare-and-select
-            // chains for the value and for the code (costs per instruction: profiles/r01_valu_class_microbench.txt)
-            // the caller passes the three key constants in place of the scores (wave-uniform, computed once per task):
-            // match -> (match - gap) * 4 + (prio(diag) - prio(left)), mismatch likewise, gap -> gap * 4 + prio(left)
-            constexpr int PU = TbCode<LOCAL>::UP, PL = TbCode<LOCAL>::LEFT;
-            const int cdm = match, cdx = mismatch, cl = gap;
-            // PERM (sequences coded 0..6, pad 7): pc[0] holds the lane's RL codes as bytes, tch arrives splatted, and
-            // `match` / `mismatch` carry the byte table (selector 0 -> cdm, 1..7 -> cdx): one v_xor + one v_perm per
-            // step and a sign-extending SDWA add per row instead of compare + select + add per row
-            uint32_t s4 = 0;
-            if (PERM) s4 = __builtin_amdgcn_perm((uint32_t)mismatch, (uint32_t)match, (uint32_t)pc[0] ^ (uint32_t)tch);
-#pragma unroll
-            for (int r = 0; r < RL; ++r) {
-                const int kd = PERM ? p_addw(dg, (int)(int8_t)(s4 >> (8 * r)))
-                                    : p_addw(dg, (pc[r] == tch) ? cdm : cdx);   // hw2.cpp:142 / 208-211: diag + s
-                const int ku = r == 0 ? up : p_addw(up, PU - PL);         // up + gap (row 0: `bottom` arrives in that form)
-                const int kl = hl[r];                                     // left + gap
-                int k = max(kd, max(ku, kl));
-                if (LOCAL) k = max(k, (int)TB_STOP);                      // the zero floor wins every tie (hw2.cpp:214)
-                const int base = k & ~3;
-                if (LOCAL) {
-                    if (base > bs[r]) {                                   // 225-229 (bs holds H * 4)
-                        bs[r] = base;
-                        bj[r] = j;
-                    }
-                } else if (EDGE && (i_first + r) == n && j == m) {
-                    res->score = k >> 2;                                  // 186
-                }
-                if (r == 0) tb_put_code<0>(codes, k);
-                if (r == 1) tb_put_code<1>(codes, k);
-                if (r == 2) tb_put_code<2>(codes, k);
-                if (r == 3) tb_put_code<3>(codes, k);
-                const int l = p_addw(base, cl);
-                dg = kl;
-                up = l;
-                hl[r] = l;
-                hnew[r] = SBAND ? (k >> 2) : 0;
-            }
-        } else if (TB) {
+        // (keyed traceback fills -- H * 4 + priority, one v_max3 per cell -- run keyed_chunk below; this step serves the plain forms)
+        static_assert(!(TB && KEYED), "keyed fills run keyed_chunk");
+        if (TB) {
             // plain int32 form with a band: the reference's own compare-and-select chains, for scores x lengths that leave
             // the keyed form's 2^28 range (any scoring the reference's `int` holds; one VALU chain per row, ~11 per cell)
             constexpr int PU = TbCode<LOCAL>::UP, PL = TbCode<LOCAL>::LEFT;
@@ -276,8 +239,8 @@ __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i
         }
         // keyed form: `bottom` (and with it the rings and hand-off rows) carries the UP-candidate form H*4 + gap*4 + prio(up),
         // what the row below feeds straight into its v_max3; diag0 stays in the left-candidate form the tables are built for
-        diag0 = (TB && KEYED) ? p_addw(up_in, TbCode<LOCAL>::LEFT - TbCode<LOCAL>::UP) : up_in;
-        bottom = (TB && KEYED) ? p_addw(up, TbCode<LOCAL>::UP - TbCode<LOCAL>::LEFT) : up;
+        diag0 = up_in;
+        bottom = up;
     } else {
 #pragma unroll
         for (int r = 0; r < RL; ++r) hnew[r] = 0;
@@ -301,6 +264,13 @@ __device__ __forceinline__ void stripe_step(int t, int lane, int m, int n, int i
 
 // ---------------------------------------------------------------------------------------------------------------
 // kCH interior steps of the KEYED form, written out in issue order.
+//
+// Keyed form: a cell's candidates are H * 4 + priority keys built with fast-class adds, and ONE v_max3 replaces the two compare-and-select
+// chains for the value and for the code (costs per instruction: profiles/r01_valu_class_microbench.txt).  The caller passes the key
+// constants in place of the scores (wave-uniform, computed once per task): match -> (match - gap) * 4 + (prio(diag) - prio(left)),
+// mismatch likewise, gap -> gap * 4 + prio(left).  PERM (sequences coded 0..6, pad 7): pc[0] holds the lane's RL codes as bytes, the text
+// symbol arrives splatted, and the two constants travel as a byte table (selector 0 -> match, 1..7 -> mismatch): one v_xor + one v_perm
+// per step and a sign-extending SDWA add per row instead of compare + select + add per row.
 //
 // A stripe is ONE wave alone on its SIMD, and the DP gives it one long dependent chain: row r's "up" candidate is row
 // r-1's fresh value, and row 0's comes from the lane above through a DPP move of the last row's value of the previous
@@ -347,12 +317,15 @@ __device__ __forceinline__ int dpp_fill_shr1(int dst, int v) { return __builtin_
 // same recurrence with gap 0 and scores s - 2 gap (ties and codes are unchanged: all three candidates of a cell shift by the same
 // gap (i + j)); with the constants known at compile time the up-candidate IS `base` and the stored value is base | prio(left):
 // 2 instead of 3 instructions behind each v_max3, 2 instead of 3 on the chain.
-template <int RL, bool LOCAL, bool SBAND, bool PERM, bool GUARD, bool GAP0 = false>
+// BAND = false (r03): the same chunk with no band at all -- scores (and end cells) of long pairs that a scores pass keeps off the strips:
+// no code bytes, no stores, one instruction per cell less.
+template <int RL, bool LOCAL, bool SBAND, bool PERM, bool GUARD, bool GAP0 = false, bool BAND = true>
 __device__ __forceinline__ void keyed_chunk(const int t0, const int lane, const int m, const int (&pc)[RL], int (&hl)[RL], int& diag0, int& bottom,
                                             int& tch, const int topv, const int tcv, int (&bs)[RL], int (&bj)[RL], const int tab_lo,
                                             const int tab_hi, const int cl, g_u8* tbs, g_i32* sbs, int* ring_out) {
     constexpr int PU = TbCode<LOCAL>::UP, PL = TbCode<LOCAL>::LEFT;
     static_assert(!GAP0 || (!LOCAL && PERM && !SBAND && PU == 0), "gap-shifted fills: global, table scoring, no score band");
+    static_assert(BAND || !SBAND, "no score band without the code band");
     const int cu = p_addw(cl, PU - PL);
     // band pointers of this lane at step t0: the unrolled steps store at immediate offsets from them
     PWA_GLOBAL uint32_t* const tb4 = (g_u32*)tbs + (size_t)t0 * 64 + lane;
@@ -386,7 +359,7 @@ __device__ __forceinline__ void keyed_chunk(const int t0, const int lane, const 
         if (RL > 1) kd[1] = diag_cand(1, hl[0], s4, tn);
         PWA_SB();
         int up = up_in, tn2 = tn;
-        uint32_t codes, s4n = s4, xn = 0;
+        uint32_t codes = 0, s4n = s4, xn = 0;
         bool have_x = false, have_s = false;
         auto chores = [&](int slot) {   // the next step's text symbol and table scores, spread over the filler slots
             if constexpr (more) {
@@ -410,10 +383,12 @@ __device__ __forceinline__ void keyed_chunk(const int t0, const int lane, const 
             chores(3 * r);
             PWA_SB();
             const int base = k & ~3;                                             // chain
-            if (r == 0) codes = tb_first_code(k);
-            if (r == 1) tb_put_code<1>(codes, k);
-            if (r == 2) tb_put_code<2>(codes, k);
-            if (r == 3) tb_put_code<3>(codes, k);
+            if constexpr (BAND) {
+                if (r == 0) codes = tb_first_code(k);
+                if (r == 1) tb_put_code<1>(codes, k);
+                if (r == 2) tb_put_code<2>(codes, k);
+                if (r == 3) tb_put_code<3>(codes, k);
+            }
             if (r == 0) {
                 const int d0 = p_addw(up_in, PL - PU);                           // chore: the next step's diagonal source of row 0
                 diag0 = act ? d0 : diag0;
@@ -447,13 +422,15 @@ __device__ __forceinline__ void keyed_chunk(const int t0, const int lane, const 
         // stores below it also separates the chain's last add from the DPP move that reads it (VALU write -> DPP read)
         if constexpr (more) upv = dpp_pick_lane0<q + 1>(kd[0], topv);
         ring_out[q] = bottom;             // lane 63: column t - 63 of the stripe's bottom row, into the ring of the stripe below
-        if (RL == 4) {
-            tb4[q * 64] = codes;
-        } else if (RL == 2) {
-            tb2[q * 64] = (uint16_t)codes;
-        } else {
+        if constexpr (BAND) {
+            if (RL == 4) {
+                tb4[q * 64] = codes;
+            } else if (RL == 2) {
+                tb2[q * 64] = (uint16_t)codes;
+            } else {
 #pragma unroll
-            for (int r = 0; r < RL; ++r) tb1[q * 64 * RL + r] = (uint8_t)(codes >> (8 * r));
+                for (int r = 0; r < RL; ++r) tb1[q * 64 * RL + r] = (uint8_t)(codes >> (8 * r));
+            }
         }
         if (SBAND) {
 #pragma unroll
@@ -506,9 +483,10 @@ struct WgShared {
     uint32_t task;
 };
 
-template <int RL, int W, bool LOCAL, bool TB, bool SBAND, bool PERM = false, bool KEYED = true, bool GAP0 = false>
+template <int RL, int W, bool LOCAL, bool TB, bool SBAND, bool PERM = false, bool KEYED = true, bool GAP0 = false, bool BAND = true>
 __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParams G) {
     static_assert(!PERM || (TB && KEYED), "table scoring exists for the keyed (traceback) form only");
+    static_assert(BAND || (TB && KEYED && PERM && !SBAND), "the band-less keyed form: scores / end cells of coded sequences");
     constexpr bool TBK = TB && KEYED;   // values travel as H * 4 + priority
     constexpr int CH = kCH;
     __shared__ WgShared<W> sh;
@@ -634,10 +612,10 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
             int diag0 = LOCAL ? 0 : p_mulw(i_first - 1, gap);           // dp[i_first-1][0]
             if (TBK) diag0 = tb_stored(diag0, gap, TbCode<LOCAL>::LEFT);
             const size_t Tb = band_steps((size_t)m);
-            g_u8* tbs = TB ? (g_u8*)(P.tb + (size_t)s * Tb * 64 * RL) : nullptr;
+            g_u8* tbs = (TB && BAND) ? (g_u8*)(P.tb + (size_t)s * Tb * 64 * RL) : nullptr;
             g_i32* sbs = SBAND ? (g_i32*)(P.sband + (size_t)s * Tb * 64 * RL) : nullptr;
             PWA_GLOBAL PairResult* res = (PWA_GLOBAL PairResult*)P.res;
-            // traceback kernels: stripe_step takes the key constants instead of the three scores
+            // traceback kernels: keyed_chunk takes the key constants instead of the three scores
             int a_match = TBK ? (int)(((unsigned)match - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - TbCode<LOCAL>::LEFT)) : match;
             int a_mismatch = TBK ? (int)(((unsigned)mismatch - (unsigned)gap) * 4u + (unsigned)(TB_DIAG - TbCode<LOCAL>::LEFT)) : mismatch;
             const int a_gap = TBK ? (int)((unsigned)gap * 4u + (unsigned)TbCode<LOCAL>::LEFT) : gap;
@@ -688,7 +666,7 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                 }
                 lds_post(&sh.taken[wave], need);
                 const bool interior = t0 >= 63 && t0 + CH < m;   // every lane inside the matrix, last column not touched
-                if (TBK) {
+                if constexpr (TBK) {
                     static_assert(kCHsteps == kCH, "keyed_chunk runs one hand-off chunk");
                     // the chunk's 16 bottom-row columns t0-63 .. t0-48 go into the ring step by step: make room first (the
                     // unclamped column count: lane 63 also writes while it is outside the matrix, and those slots must be free)
@@ -711,27 +689,29 @@ __global__ __launch_bounds__(64 * (W + 1)) void pair_fill_kernel(const PairParam
                     }
                     int* const ring_out = (has_out && lane == 63) ? rout + ring_slot(t0 - 63) : sh.dump[wave] + lane;
                     if (interior)
-                        keyed_chunk<RL, LOCAL, SBAND, PERM, false, GAP0>(t0, lane, m, pc, hl, diag0, bottom, tch, topv, tcv, bs, bj, a_match, a_mismatch,
+                        keyed_chunk<RL, LOCAL, SBAND, PERM, false, GAP0, BAND>(t0, lane, m, pc, hl, diag0, bottom, tch, topv, tcv, bs, bj, a_match, a_mismatch,
                                                                    a_gap, tbs, sbs, ring_out);
                     else
-                        keyed_chunk<RL, LOCAL, SBAND, PERM, true, GAP0>(t0, lane, m, pc, hl, diag0, bottom, tch, topv, tcv, bs, bj, a_match, a_mismatch,
+                        keyed_chunk<RL, LOCAL, SBAND, PERM, true, GAP0, BAND>(t0, lane, m, pc, hl, diag0, bottom, tch, topv, tcv, bs, bj, a_match, a_mismatch,
                                                                   a_gap, tbs, sbs, ring_out);
                     const int hi = min(m, t0 - 63 + CH);
                     if (has_out && hi > 0) lds_post_after_writes(&sh.ready[wave + 1], (uint32_t)hi);   // after the chunk's ring writes (one wave: in order)
                     continue;
-                } else if (interior) {
-#pragma unroll PWA_STEP_UNROLL
-                    for (int q = 0; q < CH; ++q)
-                        stripe_step<RL, LOCAL, TB, SBAND, false, PERM, KEYED>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
-                                                                 tcv, coll, bs, bj, a_match, a_mismatch, a_gap, tbs, sbs, res);
                 } else {
-                    const int qn = min(CH, T - t0);
+                    if (interior) {
+#pragma unroll PWA_STEP_UNROLL
+                        for (int q = 0; q < CH; ++q)
+                            stripe_step<RL, LOCAL, TB, SBAND, false, PERM, KEYED>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
+                                                                     tcv, coll, bs, bj, a_match, a_mismatch, a_gap, tbs, sbs, res);
+                    } else {
+                        const int qn = min(CH, T - t0);
 #pragma unroll 1
-                    for (int q = 0; q < qn; ++q)
-                        stripe_step<RL, LOCAL, TB, SBAND, true, PERM, KEYED>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
-                                                                tcv, coll, bs, bj, a_match, a_mismatch, a_gap, tbs, sbs, res);
+                        for (int q = 0; q < qn; ++q)
+                            stripe_step<RL, LOCAL, TB, SBAND, true, PERM, KEYED>(t0 + q, lane, m, n, i_first, pc, hl, diag0, bottom, tch, topv,
+                                                                    tcv, coll, bs, bj, a_match, a_mismatch, a_gap, tbs, sbs, res);
 #pragma unroll 1
-                    for (int q = qn; q < CH; ++q) coll = wave_shl1(bottom, coll);   // keep the collector aligned
+                        for (int q = qn; q < CH; ++q) coll = wave_shl1(bottom, coll);   // keep the collector aligned
+                    }
                 }
                 // ---- bottom row out: after the chunk lane 64-CH+q holds column t0 - 63 + q
                 if (has_out) {

@@ -24,7 +24,18 @@ static pair_kernel_t pair_fill_pick_plain_tb(bool local, bool sband) {
     if (local) return sband ? pair_fill_kernel<4, W, true, true, true, false, false> : pair_fill_kernel<4, W, true, true, false, false, false>;
     return sband ? pair_fill_kernel<4, W, false, true, true, false, false> : pair_fill_kernel<4, W, false, true, false, false, false>;
 }
-pair_kernel_t pair_fill_kernel_for(int rl, int w, bool local, bool tb, bool sband, bool perm, bool keyed, bool gap0) {
+// the keyed chunk without a band: scores (and end cells) of long pairs over a coded arena (pwalign.hip, batch_create_impl)
+template <int RL, int W>
+static pair_kernel_t pair_fill_pick_noband(bool local, bool gap0) {
+    if (local) return pair_fill_kernel<RL, W, true, true, false, true, true, false, false>;
+    return gap0 ? pair_fill_kernel<RL, W, false, true, false, true, true, true, false> : pair_fill_kernel<RL, W, false, true, false, true, true, false, false>;
+}
+pair_kernel_t pair_fill_kernel_for(int rl, int w, bool local, bool tb, bool sband, bool perm, bool keyed, bool gap0, bool band) {
+    if (!band) {
+        if (!tb || sband || !perm || !keyed) return nullptr;
+        if (rl == 2) return w == 1 ? pair_fill_pick_noband<2, 1>(local, gap0) : pair_fill_pick_noband<2, 4>(local, gap0);
+        return w == 1 ? pair_fill_pick_noband<4, 1>(local, gap0) : pair_fill_pick_noband<4, 4>(local, gap0);
+    }
     if (gap0) {   // gap-shifted global fills: table scoring, keyed, no score band
         if (local || !tb || sband || !perm || !keyed) return nullptr;
         if (rl == 2) return w == 1 ? pair_fill_kernel<2, 1, false, true, false, true, true, true> : pair_fill_kernel<2, 4, false, true, false, true, true, true>;

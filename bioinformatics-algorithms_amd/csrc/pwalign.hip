@@ -608,7 +608,10 @@ struct PairLaunch {
             G.trace_base = (uint32_t)(n_stripes * 4);
             G.trace_stripe = ctx->knobs.trace_stripe;
         }
-        const pair_kernel_t fill = pair_fill_fn(geom, local, tb, sband, perm && tb && keyed, keyed, gap0 && tb && keyed && perm && !sband && !local);
+        // (scores / end cells only over a coded arena, keys in range: the keyed chunk without a band -- batch_create_impl sets perm for that)
+        const bool noband = !tb && perm && keyed && !sband;
+        const pair_kernel_t fill = noband ? pair_fill_kernel_for(geom.rl, geom.w, local, true, false, true, true, gap0 && !local, false)
+                                          : pair_fill_fn(geom, local, tb, sband, perm && tb && keyed, keyed, gap0 && tb && keyed && perm && !sband && !local);
         if (!fill) return fail(ctx, PWA_E_INVALID, "internal: no fill kernel for this geometry");
         // A launch with no more multi-stripe workgroups than CUs asks for enough (unused) dynamic LDS that only ONE workgroup
         // fits a CU: a stripe is one wave alone on its SIMD, and every stripe of a pair moves at the pace of the slowest --
@@ -1473,14 +1476,24 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
                 for (const uint32_t k : plist) stripes2 += (slen(pair_a[k]) + 127) / 128;
                 if (geom.rl == 2 && geom.w == 4 && !ctx->knobs.force_rl && stripes2 >= 2048) geom.rl = 4;
             }
+            // a coded arena with keys in range (what the band-less mini kernels ask for as well): the keyed chunk without a band -- table
+            // scoring, one v_max3 per cell, global fills gap-shifted -- instead of the plain compare-and-select step: [gpu, r03] SW scores of
+            // 64 pairs 10k x 10k 4.8 -> 3.45 ms, NW 4.06 -> 2.05 ms; one pair 1.67 -> 1.26 / 1.55 -> 1.01 ms
+            const bool keyed_scores = mini_scores && !ctx->knobs.no_keyed_tb && !ctx->knobs.no_pair_table;
+            const bool gap0_scores = keyed_scores && mini_gap0 && !ctx->knobs.no_gap_shift;
             for (const uint32_t k : plist) {
-                pd.push_back(describe(k, q_next++));
+                PairDesc d = describe(k, q_next++);
+                d.score_bias = gap0_scores ? wrap_mul((int64_t)(slen(pair_a[k]) + slen(pair_b[k])), gap) : 0;
+                pd.push_back(d);
                 b->padded_cells += (slen(pair_a[k]) + 64 * geom.rl - 1) / (64 * geom.rl) * (64 * geom.rl) * slen(pair_b[k]);
             }
-            const int rc = b->pl.build(ctx, pd, match, mismatch, gap, geom);
+            b->pl.perm = keyed_scores;
+            b->pl.keyed = true;
+            b->pl.gap0 = gap0_scores;
+            const int rc = b->pl.build(ctx, pd, gap0_scores ? match - 2 * gap : match, gap0_scores ? mismatch - 2 * gap : mismatch, gap0_scores ? 0 : gap, geom);
             if (rc != PWA_OK) return rc;
             b->pl.G.scores_out = b->scores.as<int32_t>();   // the device score vector is complete after run()
-            names = std::string("pair_fill_kernel<RL=") + std::to_string(geom.rl) + (local ? ",SW" : ",NW") + ",no-traceback>";
+            names = std::string("pair_fill_kernel<RL=") + std::to_string(geom.rl) + (local ? ",SW" : (gap0_scores ? ",NW,GAP0" : ",NW")) + (keyed_scores ? ",keyed,no-band>" : ",no-traceback>");
         }
         for (auto& cls : mini_lists) {
             const int rl = cls.first;
