@@ -1154,7 +1154,10 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             const size_t nt0 = ht.size();
             const double vpc = (best_mode == BM_SWS ? 4.06 : best_mode == BM_SW ? 5.02 : best_mode == BM_NWG ? 2.53 : 4.5) + (score_path == SC_CMP ? 2.0 : 0.0);
             constexpr double kLoneNs = 1.9, kSimdNs = 1.63, kSimds = 1024.0;                // ns per wave instruction: one wave alone / a SIMD with two
-            const double step_ns = local ? 105.0 : 75.0, lag_us = 9.0, lone_step_ns = 100.0;   // stripe engine: per step and SIMD; per stripe of pipeline lag
+            // stripe engine: per step and SIMD; per stripe of pipeline lag; per step of a pair alone -- the keyed chunk without a band (coded
+            // arena, keys in range) or the plain step ([gpu] r03_route_probe.txt: one 10k x 10k pair 1.26 / 1.01 ms, 64 pairs 3.45 / 2.05 ms)
+            const double step_ns = mini_scores ? (local ? 70.0 : 42.0) : (local ? 105.0 : 75.0), lag_us = 9.0,
+                         lone_step_ns = mini_scores ? (local ? 55.0 : 30.0) : 100.0;
             std::vector<double> I(nt0), S(nt0), L(nt0);   // strip instructions / stripe-side work (ns x SIMD) / longest single-pair latency (us) of a task
             double I_total = 0;
             for (size_t t = 0; t < nt0; ++t) {
