@@ -20,9 +20,19 @@ def main():
               (64, 10000, 10000), (8, 30000, 30000), (4096, 100, 2000), (1024, 2000, 100)]
     if len(sys.argv) > 1:   # "pairs:n:m,..."
         shapes = [tuple(int(x) for x in t.split(":")) for t in sys.argv[1].split(",")]
-    for n_pairs, n, m in shapes:
+    for shape in shapes:
+        n_pairs, n, m = shape[:3]
+        embed = len(shape) > 3 and shape[3]   # "pairs:n:m:1": every text holds a mutated copy of its pattern (at a third of its length)
         pats = [bench.gen(1, 0, i, n) for i in range(n_pairs)]
         txts = [bench.gen(1, 1, i, m) for i in range(n_pairs)]
+        if embed:
+            for i in range(n_pairs):
+                p = bytearray(pats[i])
+                for x in range(7, len(p), 13):
+                    p[x] = b"ACGT"[(p[x] + x) & 3]
+                at = max(0, (m - n) // 3)
+                txts[i] = txts[i][:at] + bytes(p) + txts[i][at + n:]
+                txts[i] = txts[i][:m]
         packed = pkg.pack_sequences(pats + txts)
         pa = np.arange(n_pairs, dtype=np.uint32)
         pb = pa + np.uint32(n_pairs)
@@ -35,8 +45,8 @@ def main():
                 t.append((time.perf_counter() - t0) * 1e3)
             cells = n_pairs * n * m
             sys.stderr.flush()
-            print("== %6d pairs %6d x %6d %s: call %.2f ms wall (%.0f GCUPS incl. copies), checksum %d" %
-                  (n_pairs, n, m, mode, min(t), cells / min(t) / 1e6, int(out["scores"][:n_pairs].astype(np.int64).sum())), flush=True)
+            print("== %6d pairs %6d x %6d%s %s: call %.2f ms wall (%.0f GCUPS incl. copies), checksum %d" %
+                  (n_pairs, n, m, " (pattern inside)" if embed else "", mode, min(t), cells / min(t) / 1e6, int(out["scores"][:n_pairs].astype(np.int64).sum())), flush=True)
 
 
 if __name__ == "__main__":
