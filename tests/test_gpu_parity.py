@@ -1119,6 +1119,29 @@ def test_lists_of_long_patterns_take_taller_stripes(ctx):
             assert (scores[k], ovl[k]) == (want["score"], want["overlap"]), (mode, k)
 
 
+@pytest.mark.parametrize("engine", ["auto", "one pair per wave", "stripes"])
+def test_local_alignments_with_many_equal_maxima(engine):
+    """Two-letter sequences put the maximum score in many cells; hw2.cpp:225-229 starts the traceback at the FIRST one in row-major order.
+    The fills keep per-row records of packed keys (value, then the earlier step of a 16-step chunk) and reduce them over rows, lanes and
+    stripes: every class of every engine against the oracle -- op lists, start and end cells."""
+    rng = random.Random(225)
+    seqs, pa, pb = [], [], []
+    for k, n in enumerate([1, 2, 15, 16, 17, 31, 33, 64, 65, 100, 150, 160, 161, 255, 256, 257, 300, 400, 513, 700, 1024, 1025, 1500, 2100] * 3):
+        p = bytes(rng.choice(b"AC") for _ in range(n)) if k % 5 else (b"A" * n if k % 2 else b"AC" * (n // 2) + b"A" * (n % 2))
+        t = bytes(rng.choice(b"AC") for _ in range(rng.choice([1, 15, 16, 17, 40, 200, 333, 800])))
+        seqs.extend([p, t])
+        pa.append(len(seqs) - 2)
+        pb.append(len(seqs) - 1)
+    env = {"one pair per wave": {"PWA_TB_ENGINE": "2"}, "stripes": {"PWA_TB_ENGINE": "0"}}.get(engine, {})
+    with switched_context(**env) as c:
+        for sc in [(1, -1, -1), (2, -3, -5), (1, 0, 0)]:
+            res = c.align_batch("sw", seqs, pa, pb, *sc)
+            for k, r in enumerate(res):
+                want = O.align("sw", seqs[pa[k]], seqs[pb[k]], *sc, compact=True)
+                assert (r["score"], tuple(r["end"]), tuple(r["start"]), r["ops"]) == \
+                    (want["score"], tuple(want["end"]), tuple(want["start"]), want["ops"]), (engine, sc, k, len(seqs[pa[k]]), len(seqs[pb[k]]))
+
+
 def test_align_batch_cut_into_several_ranges():
     """pwa_align_batch / pwa_overlaps on a list whose bands do not fit one range (PWA_RANGE_BYTES: 3 MB here; at full size the free
     HBM decides): ranges of equal pair counts, every class present in several of them, results in caller order."""
