@@ -273,6 +273,25 @@ def test_scores_end_cells_with_ties_on_both_engines(engine):
                     assert (s[k], ei[k], ej[k]) == tuple(w), (mode, sc, k, len(seqs[pa[k]]), len(seqs[pb[k]]))
 
 
+def test_scores_end_cells_with_scores_beyond_the_byte_table(ctx):
+    """End cells over a DNA alphabet (coded arena) with scores whose key constants do not fit the byte table: no mini-stripe kernels, the
+    stripe engine's plain compare form runs on the codes (a pattern-only symbol is code 7: equal to no text code)."""
+    rng = random.Random(682)
+    seqs = [bytes(rng.choice(b"ACGT") for _ in range(rng.choice([1, 16, 100, 150, 257, 600]))) for _ in range(24)] + [b"ACGTNNNNAC" * 15]
+    pa = [rng.randrange(25) for _ in range(120)]
+    pb = [rng.randrange(24) for _ in range(120)]   # ('N' never in a text)
+    for mode in ("nw", "sw"):
+        b = ctx.batch(mode, seqs, pa, pb, 100, -90, -70, want_end=True)
+        try:
+            assert "mini_fill_kernel" not in b.info()["kernel"] and "keyed" not in b.info()["kernel"], b.info()["kernel"]
+            b.run()
+            s, ei, ej = b.fetch()
+        finally:
+            b.close()
+        for k in range(len(pa)):
+            assert (s[k], ei[k], ej[k]) == tuple(O.score(mode, seqs[pa[k]], seqs[pb[k]], 100, -90, -70)), (mode, k)
+
+
 def test_scores_end_cells_of_a_chip_filling_list_of_long_patterns(ctx):
     """Enough multi-stripe pairs to fill the chip: the stripe engine takes them at RL = 4 (fewer, taller stripes) instead of the
     RL = 2 it gives a handful of long pairs; same scores and end cells (oracle)."""
