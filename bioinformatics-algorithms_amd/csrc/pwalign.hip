@@ -2393,6 +2393,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         HIPC(ctx, cached_workspace(ctx->pool[pwa_ctx::POOL_RES], ctx->pool_bytes[pwa_ctx::POOL_RES], nc_cap * sizeof(PairResult), d_res_own, &p_res));
     }
     mark("band / ops allocation");
+    if (dbg) std::fprintf(stderr, "[pwa] bands at %p (codes, %.2f GB) %p (scores)\n", p_band, (double)band_cap / 1e9, p_sband);
     uint8_t* const d_ops = static_cast<uint8_t*>(p_ops);
     PairResult* const d_res = static_cast<PairResult*>(p_res);
     std::vector<uint8_t> host_ops;   // staging, only for ranges whose op regions do not tile
