@@ -241,6 +241,40 @@ void radix_sort_by_key(std::vector<uint64_t>& key, std::vector<uint32_t>& idx) {
 // Stable counting sort of `idx` by key(idx[i]) in [0, n_buckets): two linear passes.
 template <class KeyFn>
 void counting_sort(std::vector<uint32_t>& idx, std::vector<uint32_t>& tmp, size_t n_buckets, KeyFn key) {
+    const size_t n = idx.size();
+    if (n >= (1u << 18) && n_buckets <= (1u << 16)) {
+        // a million pairs: both passes are scattered memory accesses -- on a few threads, each with its own histogram over its own
+        // contiguous part of idx (thread t's elements of a bucket go behind those of the threads before it: still stable)
+        const int T = (int)std::min<size_t>({8, std::max(1u, std::thread::hardware_concurrency()), n >> 16});
+        std::vector<std::vector<uint32_t>> cnt((size_t)T, std::vector<uint32_t>(n_buckets, 0));
+        auto part = [&](int t) { return std::make_pair(n * (size_t)t / (size_t)T, n * (size_t)(t + 1) / (size_t)T); };
+        auto run = [&](auto&& fn) {
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; ++t) th.emplace_back(fn, t);
+            fn(0);
+            for (auto& x : th) x.join();
+        };
+        run([&](int t) {
+            const auto [a, z] = part(t);
+            uint32_t* const c = cnt[(size_t)t].data();
+            for (size_t o = a; o < z; ++o) ++c[key(idx[o])];
+        });
+        uint32_t at = 0;
+        for (size_t bkt = 0; bkt < n_buckets; ++bkt)
+            for (int t = 0; t < T; ++t) {
+                const uint32_t c = cnt[(size_t)t][bkt];
+                cnt[(size_t)t][bkt] = at;
+                at += c;
+            }
+        tmp.resize(n);
+        run([&](int t) {
+            const auto [a, z] = part(t);
+            uint32_t* const c = cnt[(size_t)t].data();
+            for (size_t o = a; o < z; ++o) tmp[c[key(idx[o])]++] = idx[o];
+        });
+        idx.swap(tmp);
+        return;
+    }
     std::vector<uint32_t> cnt(n_buckets + 1, 0);
     for (const uint32_t v : idx) ++cnt[key(v) + 1];
     for (size_t b = 0; b < n_buckets; ++b) cnt[b + 1] += cnt[b];
@@ -1159,11 +1193,20 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             const double step_ns = mini_scores ? (local ? 70.0 : 42.0) : (local ? 105.0 : 75.0), lag_us = 9.0,
                          lone_step_ns = mini_scores ? (local ? 55.0 : 30.0) : 100.0;
             std::vector<double> I(nt0), S(nt0), L(nt0);   // strip instructions / stripe-side work (ns x SIMD) / longest single-pair latency (us) of a task
-            double I_total = 0;
+            double I_total = 0, I_max = 0;
+            uint64_t filled = 0;
             for (size_t t = 0; t < nt0; ++t) {
                 const uint64_t strips = (ht[t].maxlen + bestR - 1) / bestR;
                 I[t] = (double)strips * (double)((ht[t].m + 3) / 4) * (4.0 * bestR * vpc);
                 I_total += I[t];
+                I_max = std::max(I_max, I[t]);
+                filled += ht[t].count;
+            }
+            // nothing to route when the strips' waves are many, full, and none of them dominates: per cell the strips are the cheapest engine
+            // by 2x and more, so no task can gain by leaving (and the per-pair estimates below cost ~3 ms for a million pairs)
+            const bool strips_fit = nt0 >= 4096 && filled * 10 >= (uint64_t)nt0 * 64 * 9 && I_max * kLoneNs * 4 < I_total / kSimds * kSimdNs &&
+                                    ctx->knobs.scores_route < 0;
+            for (size_t t = 0; t < nt0 && !strips_fit; ++t) {
                 double steps = 0, lat = 0;
                 for (uint32_t l = 0; l < ht[t].count; ++l) {
                     const uint32_t k = order[ht[t].first + l];
@@ -1206,12 +1249,14 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
             std::vector<uint32_t> ordA(nt0), ordB(nt0);
             std::iota(ordA.begin(), ordA.end(), 0u);
             ordB = ordA;
-            std::stable_sort(ordA.begin(), ordA.end(), [&](uint32_t x, uint32_t y) { return I[x] > I[y]; });
-            std::stable_sort(ordB.begin(), ordB.end(), [&](uint32_t x, uint32_t y) { return S[x] * I[y] < S[y] * I[x]; });   // S / I ascending
+            if (!strips_fit) {
+                std::stable_sort(ordA.begin(), ordA.end(), [&](uint32_t x, uint32_t y) { return I[x] > I[y]; });
+                std::stable_sort(ordB.begin(), ordB.end(), [&](uint32_t x, uint32_t y) { return S[x] * I[y] < S[y] * I[x]; });   // S / I ascending
+            }
             size_t kA = 0, kB = 0;
-            const double tA = evaluate(ordA, kA), tB = evaluate(ordB, kB);
+            const double tA = strips_fit ? 0.0 : evaluate(ordA, kA), tB = strips_fit ? 0.0 : evaluate(ordB, kB);
             const std::vector<uint32_t>& ord = tA <= tB ? ordA : ordB;
-            size_t kmove = tA <= tB ? kA : kB;
+            size_t kmove = strips_fit ? 0 : (tA <= tB ? kA : kB);
             if (ctx->knobs.scores_route == 1) kmove = nt0;   // tests: everything on the stripe engine
             if (dbg) std::fprintf(stderr, "[pwa] route: %zu of %zu wave tasks to the stripe engine (estimates: all on strips %.1f us, split %.1f us)\n",
                                   kmove, nt0, std::max(*std::max_element(I.begin(), I.end()) * kLoneNs, I_total / kSimds * kSimdNs) * 1e-3, std::min(tA, tB));
@@ -1265,22 +1310,38 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         }
         uint32_t max_strips = 1;
         size_t two_strip_tasks = 0;
-        for (size_t t = 0; t < nt; ++t) {
-            tasks[t].text_off = (uint32_t)aoff[ht[t].text];
-            tasks[t].text_len = (uint32_t)ht[t].m;
-            tasks[t].slot0 = (uint32_t)(t * 64);
-            tasks[t].n_strips = (uint32_t)((ht[t].maxlen + R - 1) / R);
-            max_strips = std::max(max_strips, tasks[t].n_strips);
-            two_strip_tasks += tasks[t].n_strips == 2;
-            for (uint32_t l = 0; l < ht[t].count; ++l) {
-                const uint32_t k = order[ht[t].first + l];
-                spoff[t * 64 + l] = (uint32_t)aoff[pair_a[k]];
-                splen[t * 64 + l] = (uint32_t)slen(pair_a[k]);
-                sout[t * 64 + l] = k;
-                if (b->lanes) {
-                    stoff[t * 64 + l] = (uint32_t)aoff[pair_b[k]];
-                    stlen[t * 64 + l] = (uint32_t)slen(pair_b[k]);
+        {   // (a million slots through three indirections each: on a few threads for long task lists)
+            const int T = (int)std::max<size_t>(1, std::min<size_t>({8, std::max(1u, std::thread::hardware_concurrency()), nt >> 11}));
+            std::vector<uint32_t> part_max((size_t)T, 1);
+            std::vector<size_t> part_two((size_t)T, 0);
+            auto work = [&](int th) {
+                const size_t a = nt * (size_t)th / (size_t)T, z = nt * (size_t)(th + 1) / (size_t)T;
+                for (size_t t = a; t < z; ++t) {
+                    tasks[t].text_off = (uint32_t)aoff[ht[t].text];
+                    tasks[t].text_len = (uint32_t)ht[t].m;
+                    tasks[t].slot0 = (uint32_t)(t * 64);
+                    tasks[t].n_strips = (uint32_t)((ht[t].maxlen + R - 1) / R);
+                    part_max[(size_t)th] = std::max(part_max[(size_t)th], tasks[t].n_strips);
+                    part_two[(size_t)th] += tasks[t].n_strips == 2;
+                    for (uint32_t l = 0; l < ht[t].count; ++l) {
+                        const uint32_t k = order[ht[t].first + l];
+                        spoff[t * 64 + l] = (uint32_t)aoff[pair_a[k]];
+                        splen[t * 64 + l] = (uint32_t)slen(pair_a[k]);
+                        sout[t * 64 + l] = k;
+                        if (b->lanes) {
+                            stoff[t * 64 + l] = (uint32_t)aoff[pair_b[k]];
+                            stlen[t * 64 + l] = (uint32_t)slen(pair_b[k]);
+                        }
+                    }
                 }
+            };
+            std::vector<std::thread> pool;
+            for (int th = 1; th < T; ++th) pool.emplace_back(work, th);
+            work(0);
+            for (auto& x : pool) x.join();
+            for (int th = 0; th < T; ++th) {
+                max_strips = std::max(max_strips, part_max[(size_t)th]);
+                two_strip_tasks += part_two[(size_t)th];
             }
         }
         if (b->lanes && kmode == BM_NWG) {
