@@ -1,3 +1,7 @@
+#!/bin/bash
+# A/B of the gb fill on ONE box, alternating processes: the in-tree library against build/libpwalign_oldmini.so = the same objects with
+# mini_kernels.o compiled from the commit before the packed first maxima (git archive <commit>~1 bioinformatics-algorithms_amd/csrc |
+# tar -x -C /tmp/old; hipcc ... -c /tmp/old/.../mini_kernels.hip; link with the current objects).  Result: profiles/r03_gb_fill_box_variance.txt
 source tools/gpu_steps.sh
 O=gpurun_out/r03
 mkdir -p $O
