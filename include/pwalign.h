@@ -37,12 +37,14 @@
  * reads PWA_FASTA_MIN_CHUNK -- bytes per parser chunk -- on every call.)
  *   PWA_DEBUG, PWA_PROBE          host-side phase times / nop-kernel probes on stderr
  *   PWA_SCORES_ROUTE=0|1          scores passes: 0 every pair on the strip engine, 1 every pair on the stripe engine (default: by cost)
- *   PWA_TB_ENGINE=0               traceback fills: stripe engine only (default: mini-stripe engine for patterns of <= 256 rows)
+ *   PWA_TB_ENGINE=0|2             traceback fills and scores off the strips: 0 the stripe engine's plain forms only, 2 mini-stripe kernels
+ *                                 wherever they exist (default: by the list -- patterns of <= 256 rows, and of <= 1024 rows in batches)
  *   PWA_NO_PIPELINE, PWA_PIPE_RUNS=N  one-shot score calls: runs strictly one after the other / a list that fits one arena cut into N runs
  *   PWA_ARENA_LIMIT, PWA_LANE_ROWS_LIMIT   bytes per run of the one-shot calls / per-lane text rows per batch (force the multi-run paths)
  *   PWA_RANGE_BYTES               band + op bytes per range of pwa_align_batch / pwa_overlaps (forces several ranges on a small list)
  *   PWA_NO_PAIR_TABLE, PWA_NO_KEYED_TB, PWA_NO_GAP_SHIFT, PWA_NO_TILED_OPS, PWA_NO_PACKED_DIST, PWA_PAIRED, PWA_FORCE_LANES,
- *   PWA_FORCE_R, PWA_FORCE_MODE, PWA_FORCE_RL, PWA_FORCE_W, PWA_WG_PER_CU, PWA_NO_LDS_PAD, PWA_STAMPS, PWA_TRACE_STRIPE
+ *   PWA_FORCE_R, PWA_FORCE_MODE, PWA_FORCE_RL, PWA_FORCE_W, PWA_WG_PER_CU, PWA_MINI_PER_CU, PWA_NO_LDS_PAD, PWA_STRIP_WG1, PWA_STAMPS,
+ *   PWA_TRACE_STRIPE
  *                                 select one of several equivalent kernel forms / geometries, or record time stamps
  */
 #ifndef PWALIGN_H
