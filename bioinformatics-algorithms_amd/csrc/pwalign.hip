@@ -26,6 +26,25 @@ __global__ void pwa_nop_kernel(int* p) {
     if (p && threadIdx.x == 12345) *p = 0;
 }
 
+// Symbols -> codes on the device (build_arena): n16 blocks of 16 bytes at p, every byte through the 256-entry table.  The host then only
+// copies raw bytes into the upload buffers (a memcpy instead of a table lookup per byte, which was what bounded a 570 MB arena).
+struct RecodeTable {
+    uint8_t t[256];
+};
+__global__ __launch_bounds__(256) void pwa_recode_kernel(uint8_t* p, size_t n16, const RecodeTable tab) {
+    __shared__ uint8_t lut[256];
+    lut[threadIdx.x] = tab.t[threadIdx.x];
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        uint4 v = reinterpret_cast<const uint4*>(p)[i];
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            w[d] = (uint32_t)lut[w[d] & 0xffu] | (uint32_t)lut[(w[d] >> 8) & 0xffu] << 8 | (uint32_t)lut[(w[d] >> 16) & 0xffu] << 16 | (uint32_t)lut[w[d] >> 24] << 24;
+        reinterpret_cast<uint4*>(p)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // Host-side source / destination of the library's own host <-> device copies: page-locked, grow-only, kept in the context.
 // hipMemcpy from a short-lived pageable vector works, but the runtime registers its pages with the driver for the DMA, and
 // when the vector is freed the unmap notifier evicts the process's GPU queues: the NEXT kernel submission then takes 14-24 ms
@@ -373,9 +392,19 @@ hipError_t upload_via_bounce(pwa_ctx* c, void* dst, const void* src, size_t byte
 // copied when table == nullptr -- and zeros everywhere else.  It goes up in pieces of ~32 MiB: while piece k is on its way
 // (copy stream, from one of two page-locked buffers of the context) piece k + 1 is being coded by several host threads into the
 // other -- readFasta's blob is never repacked into a second host copy, and a 570 MB arena costs 2 x 32 MiB of pinned memory.
+// r03: arenas of a MiB and more are coded ON THE DEVICE when no sequence holds a NUL byte (`nul_free`: the padding between sequences is
+// zeros and has to stay zeros, so the device table maps 0 to 0): the host threads then only copy raw bytes into the pieces and a small
+// kernel behind every piece's copy turns them into codes in place.
 hipError_t build_arena(pwa_ctx* c, void* d_arena, uint64_t arena_bytes, const uint8_t* seq_bytes, const uint64_t* seq_off, uint32_t n_seq,
-                       const std::vector<uint8_t>& is_used, const std::vector<uint64_t>& aoff, const uint8_t* table) {
+                       const std::vector<uint8_t>& is_used, const std::vector<uint64_t>& aoff, const uint8_t* table, bool nul_free = false) {
     constexpr uint64_t kPiece = 32ull << 20;
+    const bool on_device = table && nul_free && arena_bytes >= (1ull << 20) && arena_bytes % 16 == 0;
+    RecodeTable rt;
+    if (on_device) {
+        std::memcpy(rt.t, table, 256);
+        rt.t[0] = 0;
+        table = nullptr;   // the pieces take raw bytes
+    }
     std::vector<uint32_t> used;
     for (uint32_t s = 0; s < n_seq; ++s)
         if (is_used[s]) used.push_back(s);
@@ -421,6 +450,14 @@ hipError_t build_arena(pwa_ctx* c, void* d_arena, uint64_t arena_bytes, const ui
         for (auto& x : th) x.join();
         e = hipMemcpyAsync(static_cast<uint8_t*>(d_arena) + a0, host, bytes, hipMemcpyHostToDevice, c->copy_stream);
         if (e == hipSuccess) e = hipEventRecord(c->copy_ev[piece & 1], c->copy_stream);
+        if (e == hipSuccess && on_device && a0 % 16 == 0 && bytes % 16 == 0) {   // (pieces start and end on sequence regions: multiples of 16)
+            const size_t n16 = (size_t)(bytes / 16);
+            hipLaunchKernelGGL(pwa_recode_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 4096)), dim3(256), 0, c->copy_stream,
+                               static_cast<uint8_t*>(d_arena) + a0, n16, rt);
+            e = hipGetLastError();
+        } else if (e == hipSuccess && on_device) {
+            e = hipErrorInvalidValue;   // cannot happen: regions are 16-byte aligned
+        }
         u0 = u1;
     }
     const hipError_t e2 = hipStreamSynchronize(c->copy_stream);
@@ -1048,7 +1085,8 @@ static int batch_create_impl(pwa_ctx* ctx, int mode, int match, int mismatch, in
         uint8_t code8[256];
         for (int v = 0; v < 256; ++v) code8[v] = (uint8_t)(code_of[v] >= 0 ? code_of[v] : 7);
         HIPC(ctx, b->arena.alloc(arena_bytes));
-        HIPC(ctx, build_arena(ctx, b->arena.p, arena_bytes, seq_bytes, seq_off, n_seq, is_used, aoff, coded ? code8 : nullptr));
+        HIPC(ctx, build_arena(ctx, b->arena.p, arena_bytes, seq_bytes, seq_off, n_seq, is_used, aoff, coded ? code8 : nullptr,
+                              !present[0] && !pattern_has[0]));
     }
 
     mark("validate + arena upload");
@@ -2228,7 +2266,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     // (pair_fill.hip.h, PERM).  The table holds the two diagonal key constants: both must fit a signed byte.
     bool coded = false;
     uint8_t code_of[256];
-    bool dash_seen = false;
+    bool dash_seen = false, nul_seen = false;
     {
         bool seen[256] = {false};
         {   // one pass over every used byte: on a few threads once the input reaches megabytes
@@ -2251,6 +2289,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
         coded = n_alpha <= 7 && kd_match <= 127 && kd_match >= -126 && kd_mismatch <= 127 && kd_mismatch >= -126 &&
                 !ctx->knobs.no_pair_table;
         dash_seen = seen[(unsigned char)'-'];
+        nul_seen = seen[0];
     }
     // overlapLongestExactMatch (hw2.cpp:269) does not count a column whose symbols are '-' -- also when the '-' is part
     // of the input sequence itself: the walk needs the arena's value for that byte
@@ -2260,7 +2299,7 @@ static int align_batch_impl(pwa_ctx* ctx, int mode, int match, int mismatch, int
     void* p_arena = nullptr;
     {
         HIPC(ctx, cached_workspace(ctx->pool[pwa_ctx::POOL_ARENA], ctx->pool_bytes[pwa_ctx::POOL_ARENA], arena_bytes, arena_own, &p_arena));
-        HIPC(ctx, build_arena(ctx, p_arena, arena_bytes, seq_bytes, seq_off, n_seq, is_used, aoff, coded ? code_of : nullptr));
+        HIPC(ctx, build_arena(ctx, p_arena, arena_bytes, seq_bytes, seq_off, n_seq, is_used, aoff, coded ? code_of : nullptr, !nul_seen));
     }
     uint8_t* const arena_base = static_cast<uint8_t*>(p_arena);
     mark("arena upload");

@@ -1161,6 +1161,33 @@ def test_local_alignments_with_many_equal_maxima(engine):
                     (want["score"], tuple(want["end"]), tuple(want["start"]), want["ops"]), (engine, sc, k, len(seqs[pa[k]]), len(seqs[pb[k]]))
 
 
+def test_arenas_of_a_mebibyte_are_coded_on_the_device(ctx):
+    """An arena of >= 1 MiB over a small alphabet goes up as raw bytes and is turned into codes by a kernel behind every piece's copy
+    (pwalign.hip, build_arena); a NUL byte inside a sequence keeps the host's table pass (the padding between sequences is zeros).
+    Alignments and scores of a 1.2 MB list, with and without a NUL, against the oracle on a sample."""
+    rng = random.Random(1 << 20)
+    for with_nul in (False, True):
+        seqs, pa, pb = [], [], []
+        for k in range(640):
+            p = O.gen(70, 0, k, rng.choice([150, 900, 1500]))
+            t = _mutate(rng, p, 0.1)[:rng.randint(100, 1200)] + O.gen(70, 1, k, rng.randint(50, 900))
+            seqs.extend([p, t])
+            pa.append(len(seqs) - 2)
+            pb.append(len(seqs) - 1)
+        if with_nul:
+            seqs[5] = seqs[5][:40] + b"\x00" + seqs[5][41:]
+        assert sum((len(x) + 16) // 16 * 16 for x in seqs) > (1 << 20)
+        sample = sorted(rng.sample(range(640), 36) + [2])   # (pair 2 holds the NUL)
+        for mode in ("nw", "sw"):
+            res = ctx.align_batch(mode, seqs, pa, pb, 1, -1, -1)
+            got = ctx.scores(mode, seqs, pa, pb, 1, -1, -1)
+            assert got == [r["score"] for r in res]
+            for k in sample:
+                want = O.align(mode, seqs[pa[k]], seqs[pb[k]], 1, -1, -1, compact=True)
+                assert (res[k]["score"], res[k]["ops"], tuple(res[k]["end"]), tuple(res[k]["start"])) == \
+                    (want["score"], want["ops"], tuple(want["end"]), tuple(want["start"])), (with_nul, mode, k)
+
+
 def test_align_batch_cut_into_several_ranges():
     """pwa_align_batch / pwa_overlaps on a list whose bands do not fit one range (PWA_RANGE_BYTES: 3 MB here; at full size the free
     HBM decides): ranges of equal pair counts, every class present in several of them, results in caller order."""
