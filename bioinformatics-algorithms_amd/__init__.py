@@ -25,7 +25,7 @@ CLI4_PATH = os.path.join(_HERE, "host", "hw4_amd")
 MODE = {"nw": 0, "sw": 1, "global": 0, "local": 1}
 
 EXPORTS = [
-    "pwa_version", "pwa_strerror", "pwa_ctx_create", "pwa_ctx_destroy", "pwa_last_error", "pwa_ctx_set_score_band", "pwa_scores",
+    "pwa_version", "pwa_strerror", "pwa_selftest_host", "pwa_ctx_create", "pwa_ctx_destroy", "pwa_last_error", "pwa_ctx_set_score_band", "pwa_scores",
     "pwa_batch_create", "pwa_affine_batch_create", "pwa_scores_affine", "pwa_align_affine_batch", "pwa_nwdist_batch_create", "pwa_distances", "pwa_upgma_newick", "pwa_batch_run", "pwa_batch_d_scores", "pwa_batch_set_d_scores", "pwa_batch_fetch", "pwa_batch_info",
     "pwa_batch_last_ms", "pwa_batch_run_times", "pwa_batch_destroy", "pwa_align", "pwa_align_matrices", "pwa_align_last_stats", "pwa_align_batch", "pwa_overlaps",
     "pwa_cigar_bound", "pwa_mdz_bound", "pwa_format_alignment", "pwa_alignment_overlap",

@@ -762,6 +762,62 @@ extern "C" {
 
 const char* pwa_version(void) { return "pwalign 0.1 gfx950"; }
 
+// Host-only checks of the scheduler's sorting helpers (include/pwalign.h): tests call this on machines without a GPU.
+int pwa_selftest_host(uint32_t seed) try {
+    uint64_t x = 0x9e3779b97f4a7c15ull ^ seed;
+    auto rnd = [&]() {
+        x ^= x << 13;
+        x ^= x >> 7;
+        x ^= x << 17;
+        return x;
+    };
+    int check = 0;
+    for (const size_t n : {size_t(0), size_t(1), size_t(2), size_t(1000), size_t(70000), size_t(300000), size_t(1) << 20}) {
+        for (const size_t buckets : {size_t(1), size_t(3), size_t(4352), size_t(65536), size_t(200000)}) {
+            ++check;
+            std::vector<uint32_t> key(n), idx(n), tmp, want(n);
+            for (size_t i = 0; i < n; ++i) {
+                key[i] = (uint32_t)(rnd() % buckets);
+                idx[i] = (uint32_t)i;
+            }
+            want = idx;
+            std::stable_sort(want.begin(), want.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+            counting_sort(idx, tmp, buckets, [&](uint32_t v) { return (size_t)key[v]; });   // (threaded from 2^18 elements, <= 2^16 buckets)
+            if (idx != want) return check;
+        }
+        for (const uint64_t span : {uint64_t(1), uint64_t(7), uint64_t(3000), uint64_t(1) << 33}) {   // the last one takes the radix path
+            ++check;
+            std::vector<uint64_t> len(n);
+            std::vector<uint32_t> idx(n), want(n);
+            for (size_t i = 0; i < n; ++i) {
+                len[i] = 5 + rnd() % span;
+                idx[i] = (uint32_t)i;
+            }
+            want = idx;
+            std::stable_sort(want.begin(), want.end(), [&](uint32_t a, uint32_t b) { return len[a] > len[b]; });
+            sort_by_length_desc(idx, [&](uint32_t v) { return len[v]; });
+            if (idx != want) return check;
+        }
+        {
+            ++check;
+            std::vector<uint64_t> key(n);
+            std::vector<uint32_t> idx(n), want(n);
+            for (size_t i = 0; i < n; ++i) {
+                key[i] = rnd() >> (rnd() % 50);
+                idx[i] = (uint32_t)i;
+            }
+            want = idx;
+            const std::vector<uint64_t> key0 = key;
+            std::stable_sort(want.begin(), want.end(), [&](uint32_t a, uint32_t b) { return key0[a] < key0[b]; });
+            radix_sort_by_key(key, idx);
+            if (idx != want) return check;
+        }
+    }
+    return 0;
+} catch (...) {
+    return -1;
+}
+
 const char* pwa_strerror(int code) {
     switch (code) {
         case PWA_OK: return "ok";

@@ -74,6 +74,9 @@ typedef struct pwa_batch pwa_batch;
 /* Library / build identification: "pwalign <ver> gfx950". */
 const char *pwa_version(void);
 const char *pwa_strerror(int code);
+/* Test hook, no GPU involved: runs the host scheduler's sorting helpers (stable counting sort, its multi-threaded form, the length
+ * sort, the radix sort) on pseudo-random lists against std::stable_sort.  Returns 0, or the number of the first check that failed. */
+int pwa_selftest_host(uint32_t seed);
 
 /* Context = one GPU (HIP device ordinal) + its streams and workspaces. */
 int pwa_ctx_create(int device, pwa_ctx **out);

@@ -52,6 +52,16 @@ def test_dropin_library_exports_the_reference_signatures():
             assert name in ref
 
 
+def test_host_sorting_helpers_selftest():
+    """The scheduler's stable sorts (counting sort incl. its multi-threaded form, length sort, radix sort) against std::stable_sort on
+    lists of up to 2^20 elements -- inside the library, no GPU involved."""
+    L = load_pkg().lib()
+    L.pwa_selftest_host.argtypes = [C.c_uint32]
+    L.pwa_selftest_host.restype = C.c_int
+    for seed in (1, 2, 12345):
+        assert L.pwa_selftest_host(seed) == 0
+
+
 def _no_gpu():
     return not os.path.exists("/dev/kfd")
 
